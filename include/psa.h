@@ -1,0 +1,149 @@
+/*
+ * psa.h — C ABI of libpsa_amd.so, the MI355X (gfx950) implementation of the
+ * reference's GPU search engine.
+ *
+ * Every entry point is plain C: pointers, sizes, ints and doubles only.  The
+ * reference interface each one stands in for is cited as file:line into
+ * GuyKabiri/Parallel-Sequence-Alignment.
+ *
+ * Error model: the legacy symbol keeps the reference's print-and-exit
+ * behaviour (cuda_funcs.cu:44-48 pattern); everything else returns a
+ * psa_status and leaves a message in psa_last_error().  There is no CPU
+ * fallback anywhere in this library: without a usable HIP device every
+ * compute call fails with PSA_ERR_DEVICE.
+ */
+#ifndef PSA_H
+#define PSA_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "psa_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum psa_status {
+    PSA_OK            = 0,
+    PSA_ERR_ARG       = 1,  /* null pointer, empty/negative range, n < m ... */
+    PSA_ERR_ALPHABET  = 2,  /* a character outside [A-Z-] (reference quirk 16: undefined there) */
+    PSA_ERR_DEVICE    = 3,  /* HIP runtime error or no device */
+    PSA_ERR_STATE     = 4   /* call order: sequences / weights not set yet */
+} psa_status;
+
+/* Search engines. All give identical answers; they differ in speed. */
+typedef enum psa_engine {
+    PSA_ENGINE_AUTO       = 0,
+    PSA_ENGINE_SEQUENTIAL = 1, /* lane-per-offset, fp64 sum in reference order for every offset */
+    PSA_ENGINE_FILTER     = 2  /* exact integer class counts -> candidate set -> sequential re-score */
+} psa_engine;
+
+/*
+ * One search result.  32 bytes, no padding holes; this is also the record
+ * that ranks exchange in the multi-GPU fold (the reference sends
+ * {score, pid} through MPI_Allreduce(MAXLOC|MINLOC) and then the Mutant by
+ * MPI_Send/Recv, cpu_funcs.c:71-94 — here it is one record).
+ */
+typedef struct psa_result {
+    double  score;        /* total + best substitution delta; -INF (max) / +INF (min) if none */
+    int32_t offset;       /* absolute offset into seq1, -1 if none      (Mutant.offset)      */
+    int32_t char_offset;  /* index into seq2, -1 if none                (Mutant.char_offset) */
+    int32_t ch;           /* substituted character, 0 if none           (Mutant.ch)          */
+    int32_t shard;        /* which shard / rank produced it (caller-defined), -1 if unset    */
+    int64_t pairs;        /* char pairs scored to produce this record   (metric numerator)   */
+} psa_result;
+
+typedef struct psa_context psa_context;
+
+/* ---------------------------------------------------------------------------
+ * Legacy drop-in: same name, argument meaning and blocking behaviour as
+ *   double gpu_run_program(ProgramData*, Mutant*, int first_offset, int last_offset)
+ * (cuda_funcs.h:33, cuda_funcs.cu:6-146).  Searches offsets
+ * [first_offset, last_offset), returns the best total+diff, fills
+ * returned_mutant with absolute offsets; returns -INFINITY (max) / +INFINITY
+ * (min) with {-1,-1,'\0'} when nothing is found (cuda_funcs.cu:143-145,
+ * 158-161).  Never writes cpu_data, retains no pointer.  On a device error:
+ * message on stderr + exit(EXIT_FAILURE), like the reference.
+ * ProgramData must have been compiled with this library's PSA_SEQ*_MAX_LEN.
+ * ------------------------------------------------------------------------- */
+double gpu_run_program(const ProgramData* cpu_data, Mutant* returned_mutant,
+                       int first_offset, int last_offset);
+
+/* Same, for a caller whose ProgramData was compiled with other array limits
+ * (e.g. the reference's stock 10001/5001): seq1_cap/seq2_cap are that
+ * caller's SEQ1_MAX_LEN / SEQ2_MAX_LEN; field offsets are derived from them
+ * (is_max@0, weights@8, seq1@40, seq2@40+seq1_cap). */
+double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2_cap,
+                              Mutant* returned_mutant, int first_offset, int last_offset);
+
+/* ---------------------------------------------------------------------------
+ * Persistent context: owns the device buffers the reference allocates and
+ * frees on every call (cuda_funcs.cu:43-64, 122-141).  `stream` is a
+ * hipStream_t (or NULL for a stream owned by the context).
+ * ------------------------------------------------------------------------- */
+psa_status psa_create(int device, void* stream, psa_context** out);
+void       psa_destroy(psa_context* ctx);
+
+/* weights[4] in reference order (def.h:12-15), is_max as ProgramData.is_max */
+psa_status psa_set_weights(psa_context* ctx, const double weights[4], int is_max);
+/* Host sequences (copied to the device; ASCII, not necessarily NUL-terminated) */
+psa_status psa_set_seq1(psa_context* ctx, const char* seq1, int n);
+psa_status psa_set_seq2(psa_context* ctx, const char* seq2, int m);
+/* Device-resident sequences (raw ASCII bytes already in HBM, e.g. a torch
+ * uint8 tensor's data_ptr); encoded in place on the context's stream. */
+psa_status psa_set_seq1_device(psa_context* ctx, const void* d_seq1, int n);
+psa_status psa_set_seq2_device(psa_context* ctx, const void* d_seq2, int m);
+
+psa_status psa_set_engine(psa_context* ctx, psa_engine engine);
+
+/* Search offsets [first_offset, last_offset) — the body of gpu_run_program.
+ * psa_search blocks; psa_search_async enqueues on the context's stream and
+ * psa_search_wait synchronises and returns the record. */
+psa_status psa_search(psa_context* ctx, int first_offset, int last_offset, psa_result* out);
+psa_status psa_search_async(psa_context* ctx, int first_offset, int last_offset);
+psa_status psa_search_wait(psa_context* ctx, psa_result* out);
+
+/* Per-offset view for tests: scores[o-first] = total+diff of offset o,
+ * char_offsets / chs the chosen substitution (find_best_mutant_offset,
+ * cpu_funcs.c:257-300).  Arrays are host memory of last-first entries; any
+ * may be NULL. */
+psa_status psa_scores(psa_context* ctx, int first_offset, int last_offset,
+                      double* scores, int32_t* char_offsets, int32_t* chs);
+
+/* Fold of per-shard records with the reference's merge order
+ * (is_swapable, cuda_funcs.cu:290-307: strictly better score, then lower
+ * offset, then lower char_offset).  Host-only, no device needed. */
+psa_status psa_fold(const psa_result* records, int count, int is_max, psa_result* out);
+
+/* Offset slice of shard `rank` of `nshards` over `total_offsets`
+ * (cpu_funcs.c:128-133: equal slices, the last shard takes the remainder). */
+void psa_shard_range(int total_offsets, int nshards, int rank, int* first_offset, int* last_offset);
+
+/* Host-built 27x27 tables (index [c1][c2] with 'A'..'Z' -> 0..25, '-' -> 26,
+ * row stride 32): pair score P (get_weight(get_hashtable_sign), cuda_funcs.cu:
+ * 424-452), substitute SUB (get_substitute, cuda_funcs.cu:310-421) and
+ * DELTA = weight(sign(c1,SUB)) - P (cpu_funcs.c:285).  Any may be NULL. */
+psa_status psa_build_tables(const double weights[4], int is_max,
+                            double* P, unsigned char* SUB, double* DELTA, char* SIGN);
+
+/* Timing of the last search's kernels, measured with HIP events on the
+ * context's stream when profiling is on: which = 0 whole search, 1 dominant
+ * kernel.  kernel_name may be NULL. */
+psa_status psa_set_profiling(psa_context* ctx, int on);
+psa_status psa_last_timing(psa_context* ctx, int which, float* milliseconds, const char** kernel_name);
+/* Sums over every search completed (psa_search / psa_search_wait) since
+ * profiling was switched on: whole-search ms, dominant-kernel ms, count. */
+psa_status psa_profile_totals(psa_context* ctx, double* search_ms, double* kernel_ms, int* searches);
+
+/* Deterministic synthetic sequence: n letters uniform over 'A'..'Z'
+ * (the distribution of the reference's own generator, main.c:73,81) from a
+ * counter-based SplitMix64 stream; NUL-terminates out[n]. */
+void psa_generate_sequence(uint64_t seed, int n, char* out);
+
+const char* psa_last_error(void);
+const char* psa_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSA_H */

@@ -1,0 +1,789 @@
+// psa_device.hip — gfx950 kernels and the device half of the C ABI.
+//
+// Engine "sequential" (this file, round 1): one lane per offset (R offsets
+// per lane), the char axis walked in index order, the pair score looked up in
+// an LDS-resident 32x32 fp64 table and added with a plain v_add_f64 — the
+// same additions in the same order as find_best_mutant_offset
+// (cpu_funcs.c:271-295), so per-offset totals are bit-identical to the
+// reference CPU path and near-tied offsets resolve the same way.
+// The substitution delta has at most 10 distinct values per (weights, mode);
+// the kernel tracks only the best delta *rank* per offset (integer max), the
+// substituted position/character is recovered for the winner alone.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+
+#include "psa_internal.hpp"
+
+namespace psa {
+
+constexpr int kBlock = 256;
+constexpr int kSeq1Pad = 4096;   // code-27 tail behind Seq1 so tile over-reads stay in bounds
+
+struct BlockRec {     // per-block / per-shard arg-best
+    double score;
+    int    offset;    // INT_MAX = none
+    int    rank;
+};
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ bool rec_better(bool is_max, double s_new, int o_new, double s_old, int o_old)
+{
+    // is_swapable (cuda_funcs.cu:290-307) restricted to (score, offset):
+    // strictly better score, or equal score and lower offset.
+    if (is_max ? (s_new > s_old) : (s_new < s_old)) return true;
+    return s_new == s_old && o_new < o_old;
+}
+
+__device__ __forceinline__ void wave_fold(bool is_max, double& s, int& o, int& r)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const double s2 = __shfl_xor(s, d, 64);
+        const int o2 = __shfl_xor(o, d, 64);
+        const int r2 = __shfl_xor(r, d, 64);
+        if (rec_better(is_max, s2, o2, s, o)) { s = s2; o = o2; r = r2; }
+    }
+}
+
+// Block-wide fold; result valid in thread 0.  scratch: kBlock/64 records.
+__device__ __forceinline__ void block_fold(bool is_max, double& s, int& o, int& r, BlockRec* scratch)
+{
+    wave_fold(is_max, s, o, r);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { scratch[wave].score = s; scratch[wave].offset = o; scratch[wave].rank = r; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w)
+            if (rec_better(is_max, scratch[w].score, scratch[w].offset, s, o)) {
+                s = scratch[w].score; o = scratch[w].offset; r = scratch[w].rank;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// encode kernels: ASCII -> codes (psa_internal.hpp), flag anything else
+// ---------------------------------------------------------------------------
+__global__ void psa_encode_seq1(const unsigned char* __restrict__ raw, int n, unsigned char* __restrict__ codes,
+                                int capacity, int* __restrict__ bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= capacity) return;
+    int code = kCodePad;
+    if (i < n) {
+        const unsigned char c = raw[i];
+        code = (c >= 'A' && c <= 'Z') ? c - 'A' : (c == '-' ? kCodeHyphen : kCodeBad);
+        if (code == kCodeBad) { atomicOr(bad, 1); code = kCodePad; }
+    }
+    codes[i] = (unsigned char)code;
+}
+
+__global__ void psa_encode_seq2(const unsigned char* __restrict__ raw, int m, unsigned int* __restrict__ rows,
+                                int capacity, int* __restrict__ bad)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= capacity) return;
+    int code = kCodePad;
+    if (i < m) {
+        const unsigned char c = raw[i];
+        code = (c >= 'A' && c <= 'Z') ? c - 'A' : (c == '-' ? kCodeHyphen : kCodeBad);
+        if (code == kCodeBad) { atomicOr(bad, 2); code = kCodePad; }
+    }
+    rows[i] = (unsigned int)code;
+}
+
+// ---------------------------------------------------------------------------
+// sequential engine
+// ---------------------------------------------------------------------------
+struct SeqArgs {
+    const unsigned char* s1;      // codes, padded with kCodePad
+    const unsigned int*  s2rows;  // codes of Seq2, padded to a multiple of 4 with kCodePad
+    const double*        pair;    // [32][32] fp64, [c2][c1]
+    const unsigned char* rank;    // [32][32]
+    const double*        delta_of_rank;  // [kMaxRanks]
+    BlockRec*            block_out;      // one record per block
+    double*              per_score;      // optional per-offset outputs (index o - first)
+    unsigned char*       per_rank;
+    int m;        // chars
+    int m4;       // m rounded up to a multiple of 4
+    int first;    // offset range [first, last)
+    int last;
+    int base;     // first rounded down to a multiple of 4 (lane 0's first offset)
+    int is_max;
+};
+
+template <int R>
+__global__ __launch_bounds__(kBlock) void psa_seq_kernel(SeqArgs a)
+{
+    __shared__ double        s_pair[kRow * kRow];
+    __shared__ unsigned char s_rank[kRow * kRow];
+    __shared__ double        s_delta[kMaxRanks];
+    __shared__ BlockRec      s_fold[kBlock / 64];
+
+    for (int k = threadIdx.x; k < kRow * kRow; k += kBlock) {
+        s_pair[k] = a.pair[k];
+        s_rank[k] = a.rank[k];
+    }
+    if (threadIdx.x < kMaxRanks) s_delta[threadIdx.x] = a.delta_of_rank[threadIdx.x];
+    __syncthreads();
+
+    const int lane_id = blockIdx.x * kBlock + threadIdx.x;
+    const int o0 = a.base + R * lane_id;              // this lane's offsets: o0 .. o0+R-1
+    const unsigned char* p = a.s1 + o0;
+
+    double acc[R];
+    unsigned int best[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { acc[r] = 0.0; best[r] = 0u; }
+
+    // Window of Seq1 codes for chars i0..i0+3 of all R offsets: bytes
+    // o0+i0 .. o0+i0+R+2, held in (d0, d1).
+    unsigned int d0 = *reinterpret_cast<const unsigned int*>(p);
+    for (int i0 = 0; i0 < a.m4; i0 += 4) {
+        const unsigned int d1 = *reinterpret_cast<const unsigned int*>(p + i0 + 4);
+        const uint4 rows = *reinterpret_cast<const uint4*>(a.s2rows + i0);   // wave-uniform -> scalar load
+        const unsigned long long win = ((unsigned long long)d1 << 32) | d0;
+        const unsigned int row[4] = {rows.x, rows.y, rows.z, rows.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const unsigned int c1 = (unsigned int)(win >> (8 * (r + k))) & 0xffu;
+                const unsigned int idx = row[k] * kRow + c1;
+                acc[r] += s_pair[idx];                       // reference order: i ascending
+                const unsigned int rk = s_rank[idx];
+                best[r] = rk > best[r] ? rk : best[r];
+            }
+        }
+        d0 = d1;
+    }
+
+    // per-offset score = total + best delta (cpu_funcs.c:297-299)
+    const bool is_max = a.is_max != 0;
+    double my_s = is_max ? -INFINITY : INFINITY;
+    int my_o = INT_MAX, my_r = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int o = o0 + r;
+        if (o >= a.first && o < a.last) {
+            const double s = best[r] ? acc[r] + s_delta[best[r]] : s_delta[0];
+            if (a.per_score) a.per_score[o - a.first] = s;
+            if (a.per_rank) a.per_rank[o - a.first] = (unsigned char)best[r];
+            if (rec_better(is_max, s, o, my_s, my_o)) { my_s = s; my_o = o; my_r = (int)best[r]; }
+        }
+    }
+    block_fold(is_max, my_s, my_o, my_r, s_fold);
+    if (threadIdx.x == 0) {
+        a.block_out[blockIdx.x].score = my_s;
+        a.block_out[blockIdx.x].offset = my_o;
+        a.block_out[blockIdx.x].rank = my_r;
+    }
+}
+
+// Folds the per-block records, then recovers the winner's substitution:
+// the first i whose delta rank equals the offset's best rank
+// (cpu_funcs.c:287-294: strict compare keeps the lowest i).
+struct FinalArgs {
+    const BlockRec*      block_in;
+    int                  nblocks;
+    const unsigned char* s1;
+    const unsigned int*  s2rows;
+    const unsigned char* rank;
+    const unsigned char* sub;
+    psa_result*          out;
+    int m;
+    int is_max;
+    long long pairs;
+};
+
+__global__ __launch_bounds__(kBlock) void psa_finalize_kernel(FinalArgs a)
+{
+    __shared__ BlockRec s_fold[kBlock / 64];
+    __shared__ BlockRec s_win;
+    __shared__ int s_first_i;
+    const bool is_max = a.is_max != 0;
+
+    double s = is_max ? -INFINITY : INFINITY;
+    int o = INT_MAX, r = 0;
+    for (int k = threadIdx.x; k < a.nblocks; k += kBlock) {
+        const BlockRec b = a.block_in[k];
+        if (rec_better(is_max, b.score, b.offset, s, o)) { s = b.score; o = b.offset; r = b.rank; }
+    }
+    block_fold(is_max, s, o, r, s_fold);
+    if (threadIdx.x == 0) {
+        s_win.score = s; s_win.offset = o; s_win.rank = r;
+        s_first_i = INT_MAX;
+    }
+    __syncthreads();
+    const BlockRec w = s_win;
+    if (w.offset == INT_MAX || w.rank == 0) {
+        if (threadIdx.x == 0) {
+            a.out->score = is_max ? -INFINITY : INFINITY;
+            a.out->offset = -1;
+            a.out->char_offset = -1;
+            a.out->ch = 0;
+            a.out->shard = -1;
+            a.out->pairs = a.pairs;
+        }
+        return;
+    }
+    int mine = INT_MAX;
+    for (int i = threadIdx.x; i < a.m; i += kBlock) {
+        const unsigned int idx = a.s2rows[i] * kRow + a.s1[w.offset + i];
+        if (a.rank[idx] == w.rank) { mine = i; break; }
+    }
+    atomicMin(&s_first_i, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int i = s_first_i;
+        const unsigned int idx = a.s2rows[i] * kRow + a.s1[w.offset + i];
+        a.out->score = w.score;
+        a.out->offset = w.offset;
+        a.out->char_offset = i;
+        a.out->ch = a.sub[idx];
+        a.out->shard = -1;
+        a.out->pairs = a.pairs;
+    }
+}
+
+// test view: substitution of every offset (first i of the offset's best rank)
+__global__ void psa_first_index_kernel(const unsigned char* __restrict__ s1, const unsigned int* __restrict__ s2rows,
+                                       const unsigned char* __restrict__ rank, const unsigned char* __restrict__ sub,
+                                       const unsigned char* __restrict__ per_rank, int first, int last, int m,
+                                       int* __restrict__ char_offsets, int* __restrict__ chs)
+{
+    const int o = first + blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= last) return;
+    const unsigned int want = per_rank[o - first];
+    int found = -1, ch = 0;
+    if (want)
+        for (int i = 0; i < m; ++i) {
+            const unsigned int idx = s2rows[i] * kRow + s1[o + i];
+            if (rank[idx] == want) { found = i; ch = sub[idx]; break; }
+        }
+    char_offsets[o - first] = found;
+    chs[o - first] = ch;
+}
+
+}  // namespace psa
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+using psa::set_last_error;
+
+#define PSA_HIP(call)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (call);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            set_last_error(std::string(#call) + ": " + hipGetErrorString(e_));                 \
+            return PSA_ERR_DEVICE;                                                             \
+        }                                                                                      \
+    } while (0)
+
+struct psa_context {
+    int         device = 0;
+    hipStream_t stream = nullptr;
+    bool        own_stream = false;
+
+    psa::Tables tables;
+    bool        have_weights = false;
+    int         n = -1, m = -1;
+    int         n_cap = 0, m_cap = 0;        // allocated code capacities
+
+    unsigned char* d_raw = nullptr;  size_t raw_cap = 0;   // staging for host sequences
+    unsigned char* d_s1 = nullptr;
+    unsigned int*  d_s2rows = nullptr;
+    double*        d_pair = nullptr;
+    unsigned char* d_rank = nullptr;
+    unsigned char* d_sub = nullptr;
+    double*        d_delta = nullptr;
+    psa::BlockRec* d_blocks = nullptr;  int blocks_cap = 0;
+    psa_result*    d_result = nullptr;
+    psa_result*    h_result = nullptr;   // pinned
+    int*           d_bad = nullptr;
+    int*           h_bad = nullptr;      // pinned
+
+    psa_engine  engine = PSA_ENGINE_AUTO;
+    int         forced_r = 0;
+
+    bool        profiling = false;
+    hipEvent_t  ev[4] = {nullptr, nullptr, nullptr, nullptr};   // search start/stop, kernel start/stop
+    bool        timing_valid = false;
+    const char* last_kernel = "";
+    bool        pending = false;
+    double      sum_search_ms = 0.0, sum_kernel_ms = 0.0;   // over profiled searches since profiling was switched on
+    int         profiled = 0;
+};
+
+namespace {
+
+psa_status ensure_device(psa_context* c)
+{
+    PSA_HIP(hipSetDevice(c->device));
+    return PSA_OK;
+}
+
+psa_status upload_tables(psa_context* c)
+{
+    const psa::Tables& t = c->tables;
+    PSA_HIP(hipMemcpyAsync(c->d_pair, t.pair, sizeof t.pair, hipMemcpyHostToDevice, c->stream));
+    PSA_HIP(hipMemcpyAsync(c->d_rank, t.rank, sizeof t.rank, hipMemcpyHostToDevice, c->stream));
+    PSA_HIP(hipMemcpyAsync(c->d_sub, t.sub, sizeof t.sub, hipMemcpyHostToDevice, c->stream));
+    PSA_HIP(hipMemcpyAsync(c->d_delta, t.delta_of_rank, sizeof t.delta_of_rank, hipMemcpyHostToDevice, c->stream));
+    PSA_HIP(hipStreamSynchronize(c->stream));   // host arrays may change right after return
+    return PSA_OK;
+}
+
+psa_status check_bad(psa_context* c, int bit, const char* what)
+{
+    PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PSA_HIP(hipStreamSynchronize(c->stream));
+    if (*c->h_bad & bit) {
+        PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
+        set_last_error(std::string(what) + " contains a character outside [A-Z-]");
+        return PSA_ERR_ALPHABET;
+    }
+    return PSA_OK;
+}
+
+psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
+{
+    const int need = n + psa::kSeq1Pad;
+    if (need > c->n_cap) {
+        if (c->d_s1) PSA_HIP(hipFree(c->d_s1));
+        c->d_s1 = nullptr;
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_s1), need));
+        c->n_cap = need;
+    }
+    c->n = -1;
+    hipLaunchKernelGGL(psa::psa_encode_seq1, dim3((c->n_cap + 255) / 256), dim3(256), 0, c->stream,
+                       static_cast<const unsigned char*>(d_raw), n, c->d_s1, c->n_cap, c->d_bad);
+    PSA_HIP(hipGetLastError());
+    psa_status st = check_bad(c, 1, "seq1");
+    if (st != PSA_OK) return st;
+    c->n = n;
+    return PSA_OK;
+}
+
+psa_status encode_seq2(psa_context* c, const void* d_raw, int m)
+{
+    const int need = ((m + 3) & ~3) + 64;
+    if (need > c->m_cap) {
+        if (c->d_s2rows) PSA_HIP(hipFree(c->d_s2rows));
+        c->d_s2rows = nullptr;
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_s2rows), sizeof(unsigned int) * need));
+        c->m_cap = need;
+    }
+    c->m = -1;
+    hipLaunchKernelGGL(psa::psa_encode_seq2, dim3((c->m_cap + 255) / 256), dim3(256), 0, c->stream,
+                       static_cast<const unsigned char*>(d_raw), m, c->d_s2rows, c->m_cap, c->d_bad);
+    PSA_HIP(hipGetLastError());
+    psa_status st = check_bad(c, 2, "seq2");
+    if (st != PSA_OK) return st;
+    c->m = m;
+    return PSA_OK;
+}
+
+psa_status stage_host(psa_context* c, const char* host, int len)
+{
+    if ((size_t)len > c->raw_cap) {
+        if (c->d_raw) PSA_HIP(hipFree(c->d_raw));
+        c->d_raw = nullptr;
+        c->raw_cap = 0;
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_raw), (size_t)len + 64));
+        c->raw_cap = (size_t)len + 64;
+    }
+    PSA_HIP(hipMemcpyAsync(c->d_raw, host, len, hipMemcpyHostToDevice, c->stream));
+    return PSA_OK;
+}
+
+int pick_r(const psa_context* c, int span)
+{
+    if (c->forced_r == 1 || c->forced_r == 2 || c->forced_r == 4) return c->forced_r;
+    // 1024 SIMDs; keep >= ~3 waves per SIMD before widening the per-lane tile
+    if (span >= 4 * 64 * 3072) return 4;
+    if (span >= 2 * 64 * 3072) return 2;
+    return 1;
+}
+
+psa_status launch_sequential(psa_context* c, int first, int last, double* per_score, unsigned char* per_rank)
+{
+    const int span = last - first;
+    const int r = pick_r(c, span);
+    const int base = first & ~3;
+    const int lanes = (last - base + r - 1) / r;
+    const int nblocks = (lanes + psa::kBlock - 1) / psa::kBlock;
+    if (nblocks > c->blocks_cap) {
+        if (c->d_blocks) PSA_HIP(hipFree(c->d_blocks));
+        c->d_blocks = nullptr;
+        c->blocks_cap = 0;
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_blocks), sizeof(psa::BlockRec) * (size_t)nblocks));
+        c->blocks_cap = nblocks;
+    }
+    psa::SeqArgs a;
+    a.s1 = c->d_s1;
+    a.s2rows = c->d_s2rows;
+    a.pair = c->d_pair;
+    a.rank = c->d_rank;
+    a.delta_of_rank = c->d_delta;
+    a.block_out = c->d_blocks;
+    a.per_score = per_score;
+    a.per_rank = per_rank;
+    a.m = c->m;
+    a.m4 = (c->m + 3) & ~3;
+    a.first = first;
+    a.last = last;
+    a.base = base;
+    a.is_max = c->tables.is_max;
+
+    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[2], c->stream));
+    switch (r) {
+    case 4:
+        hipLaunchKernelGGL(psa::psa_seq_kernel<4>, dim3(nblocks), dim3(psa::kBlock), 0, c->stream, a);
+        c->last_kernel = "psa_seq_kernel<4>";
+        break;
+    case 2:
+        hipLaunchKernelGGL(psa::psa_seq_kernel<2>, dim3(nblocks), dim3(psa::kBlock), 0, c->stream, a);
+        c->last_kernel = "psa_seq_kernel<2>";
+        break;
+    default:
+        hipLaunchKernelGGL(psa::psa_seq_kernel<1>, dim3(nblocks), dim3(psa::kBlock), 0, c->stream, a);
+        c->last_kernel = "psa_seq_kernel<1>";
+        break;
+    }
+    PSA_HIP(hipGetLastError());
+    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[3], c->stream));
+
+    psa::FinalArgs f;
+    f.block_in = c->d_blocks;
+    f.nblocks = nblocks;
+    f.s1 = c->d_s1;
+    f.s2rows = c->d_s2rows;
+    f.rank = c->d_rank;
+    f.sub = c->d_sub;
+    f.out = c->d_result;
+    f.m = c->m;
+    f.is_max = c->tables.is_max;
+    f.pairs = (long long)span * (long long)c->m;
+    hipLaunchKernelGGL(psa::psa_finalize_kernel, dim3(1), dim3(psa::kBlock), 0, c->stream, f);
+    PSA_HIP(hipGetLastError());
+    return PSA_OK;
+}
+
+psa_status check_ready(psa_context* c, int first, int last)
+{
+    if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
+    if (!c->have_weights || c->n < 0 || c->m < 0) {
+        set_last_error("weights, seq1 and seq2 must be set before a search");
+        return PSA_ERR_STATE;
+    }
+    const long long total = (long long)c->n - c->m + 1;
+    if (c->m < 1 || total < 1) {
+        set_last_error("need 1 <= len(seq2) <= len(seq1)");
+        return PSA_ERR_ARG;
+    }
+    if (first < 0 || last > total || first >= last) {
+        set_last_error("offset range must satisfy 0 <= first < last <= len(seq1)-len(seq2)+1");
+        return PSA_ERR_ARG;
+    }
+    return PSA_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+psa_status psa_create(int device, void* stream, psa_context** out)
+{
+    if (!out) { set_last_error("psa_create: out is NULL"); return PSA_ERR_ARG; }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count < 1) {
+        set_last_error(std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0"));
+        return PSA_ERR_DEVICE;
+    }
+    if (device < 0 || device >= count) { set_last_error("psa_create: device index out of range"); return PSA_ERR_ARG; }
+    psa_context* c = new psa_context();
+    c->device = device;
+    psa_status st = [&]() -> psa_status {
+        PSA_HIP(hipSetDevice(device));
+        if (stream) c->stream = static_cast<hipStream_t>(stream);
+        else {
+            PSA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+            c->own_stream = true;
+        }
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_pair), sizeof(double) * psa::kRow * psa::kRow));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_rank), psa::kRow * psa::kRow));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_sub), psa::kRow * psa::kRow));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_delta), sizeof(double) * psa::kMaxRanks));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_result), sizeof(psa_result)));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bad), sizeof(int)));
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_result), sizeof(psa_result), hipHostMallocDefault));
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_bad), sizeof(int), hipHostMallocDefault));
+        PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
+        for (auto& ev : c->ev) PSA_HIP(hipEventCreate(&ev));
+        PSA_HIP(hipStreamSynchronize(c->stream));
+        return PSA_OK;
+    }();
+    if (st != PSA_OK) { psa_destroy(c); return st; }
+    if (const char* r = std::getenv("PSA_SEQ_R")) c->forced_r = std::atoi(r);
+    *out = c;
+    return PSA_OK;
+}
+
+void psa_destroy(psa_context* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_raw);
+    (void)hipFree(c->d_s1);
+    (void)hipFree(c->d_s2rows);
+    (void)hipFree(c->d_pair);
+    (void)hipFree(c->d_rank);
+    (void)hipFree(c->d_sub);
+    (void)hipFree(c->d_delta);
+    (void)hipFree(c->d_blocks);
+    (void)hipFree(c->d_result);
+    (void)hipFree(c->d_bad);
+    if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->h_bad) (void)hipHostFree(c->h_bad);
+    for (auto& ev : c->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+psa_status psa_set_weights(psa_context* c, const double weights[4], int is_max)
+{
+    if (!c || !weights) { set_last_error("psa_set_weights: NULL argument"); return PSA_ERR_ARG; }
+    std::string err;
+    psa::Tables t;
+    if (!psa::build_tables(weights, is_max, &t, &err)) { set_last_error(err); return PSA_ERR_ARG; }
+    psa_status st = ensure_device(c);
+    if (st != PSA_OK) return st;
+    c->tables = t;
+    st = upload_tables(c);
+    if (st != PSA_OK) return st;
+    c->have_weights = true;
+    return PSA_OK;
+}
+
+psa_status psa_set_seq1_device(psa_context* c, const void* d_seq1, int n)
+{
+    if (!c || !d_seq1 || n < 1) { set_last_error("psa_set_seq1: bad arguments"); return PSA_ERR_ARG; }
+    psa_status st = ensure_device(c);
+    if (st != PSA_OK) return st;
+    return encode_seq1(c, d_seq1, n);
+}
+
+psa_status psa_set_seq2_device(psa_context* c, const void* d_seq2, int m)
+{
+    if (!c || !d_seq2 || m < 1) { set_last_error("psa_set_seq2: bad arguments"); return PSA_ERR_ARG; }
+    psa_status st = ensure_device(c);
+    if (st != PSA_OK) return st;
+    return encode_seq2(c, d_seq2, m);
+}
+
+psa_status psa_set_seq1(psa_context* c, const char* seq1, int n)
+{
+    if (!c || !seq1 || n < 1) { set_last_error("psa_set_seq1: bad arguments"); return PSA_ERR_ARG; }
+    psa_status st = ensure_device(c);
+    if (st != PSA_OK) return st;
+    st = stage_host(c, seq1, n);
+    if (st != PSA_OK) return st;
+    return encode_seq1(c, c->d_raw, n);
+}
+
+psa_status psa_set_seq2(psa_context* c, const char* seq2, int m)
+{
+    if (!c || !seq2 || m < 1) { set_last_error("psa_set_seq2: bad arguments"); return PSA_ERR_ARG; }
+    psa_status st = ensure_device(c);
+    if (st != PSA_OK) return st;
+    st = stage_host(c, seq2, m);
+    if (st != PSA_OK) return st;
+    return encode_seq2(c, c->d_raw, m);
+}
+
+psa_status psa_set_engine(psa_context* c, psa_engine engine)
+{
+    if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
+    c->engine = engine;
+    return PSA_OK;
+}
+
+psa_status psa_search_async(psa_context* c, int first, int last)
+{
+    psa_status st = check_ready(c, first, last);
+    if (st != PSA_OK) return st;
+    st = ensure_device(c);
+    if (st != PSA_OK) return st;
+    c->timing_valid = false;
+    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[0], c->stream));
+    st = launch_sequential(c, first, last, nullptr, nullptr);
+    if (st != PSA_OK) return st;
+    PSA_HIP(hipMemcpyAsync(c->h_result, c->d_result, sizeof(psa_result), hipMemcpyDeviceToHost, c->stream));
+    if (c->profiling) {
+        PSA_HIP(hipEventRecord(c->ev[1], c->stream));
+        c->timing_valid = true;
+    }
+    c->pending = true;
+    return PSA_OK;
+}
+
+psa_status psa_search_wait(psa_context* c, psa_result* out)
+{
+    if (!c || !out) { set_last_error("psa_search_wait: NULL argument"); return PSA_ERR_ARG; }
+    if (!c->pending) { set_last_error("psa_search_wait: no search in flight"); return PSA_ERR_STATE; }
+    PSA_HIP(hipStreamSynchronize(c->stream));
+    c->pending = false;
+    *out = *c->h_result;
+    if (c->profiling && c->timing_valid) {
+        float a = 0.f, b = 0.f;
+        PSA_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+        PSA_HIP(hipEventElapsedTime(&b, c->ev[2], c->ev[3]));
+        c->sum_search_ms += a;
+        c->sum_kernel_ms += b;
+        c->profiled += 1;
+    }
+    return PSA_OK;
+}
+
+psa_status psa_search(psa_context* c, int first, int last, psa_result* out)
+{
+    psa_status st = psa_search_async(c, first, last);
+    if (st != PSA_OK) return st;
+    return psa_search_wait(c, out);
+}
+
+psa_status psa_scores(psa_context* c, int first, int last, double* scores, int32_t* char_offsets, int32_t* chs)
+{
+    psa_status st = check_ready(c, first, last);
+    if (st != PSA_OK) return st;
+    st = ensure_device(c);
+    if (st != PSA_OK) return st;
+    const int span = last - first;
+    double* d_score = nullptr;
+    unsigned char* d_prank = nullptr;
+    int* d_ci = nullptr;
+    int* d_ch = nullptr;
+    st = [&]() -> psa_status {
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_score), sizeof(double) * (size_t)span));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_prank), (size_t)span));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_ci), sizeof(int) * (size_t)span));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_ch), sizeof(int) * (size_t)span));
+        psa_status s2 = launch_sequential(c, first, last, d_score, d_prank);
+        if (s2 != PSA_OK) return s2;
+        hipLaunchKernelGGL(psa::psa_first_index_kernel, dim3((span + 255) / 256), dim3(256), 0, c->stream,
+                           c->d_s1, c->d_s2rows, c->d_rank, c->d_sub, d_prank, first, last, c->m, d_ci, d_ch);
+        PSA_HIP(hipGetLastError());
+        if (scores) PSA_HIP(hipMemcpyAsync(scores, d_score, sizeof(double) * (size_t)span, hipMemcpyDeviceToHost, c->stream));
+        if (char_offsets) PSA_HIP(hipMemcpyAsync(char_offsets, d_ci, sizeof(int) * (size_t)span, hipMemcpyDeviceToHost, c->stream));
+        if (chs) PSA_HIP(hipMemcpyAsync(chs, d_ch, sizeof(int) * (size_t)span, hipMemcpyDeviceToHost, c->stream));
+        PSA_HIP(hipStreamSynchronize(c->stream));
+        return PSA_OK;
+    }();
+    (void)hipFree(d_score);
+    (void)hipFree(d_prank);
+    (void)hipFree(d_ci);
+    (void)hipFree(d_ch);
+    return st;
+}
+
+psa_status psa_set_profiling(psa_context* c, int on)
+{
+    if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
+    c->profiling = on != 0;
+    c->timing_valid = false;
+    c->sum_search_ms = c->sum_kernel_ms = 0.0;
+    c->profiled = 0;
+    return PSA_OK;
+}
+
+psa_status psa_profile_totals(psa_context* c, double* search_ms, double* kernel_ms, int* searches)
+{
+    if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
+    if (search_ms) *search_ms = c->sum_search_ms;
+    if (kernel_ms) *kernel_ms = c->sum_kernel_ms;
+    if (searches) *searches = c->profiled;
+    return PSA_OK;
+}
+
+psa_status psa_last_timing(psa_context* c, int which, float* ms, const char** kernel_name)
+{
+    if (!c || !ms) { set_last_error("psa_last_timing: NULL argument"); return PSA_ERR_ARG; }
+    if (!c->timing_valid) { set_last_error("psa_last_timing: profiling was off for the last search"); return PSA_ERR_STATE; }
+    PSA_HIP(hipEventSynchronize(c->ev[1]));
+    if (which == 0) PSA_HIP(hipEventElapsedTime(ms, c->ev[0], c->ev[1]));
+    else PSA_HIP(hipEventElapsedTime(ms, c->ev[2], c->ev[3]));
+    if (kernel_name) *kernel_name = c->last_kernel;
+    return PSA_OK;
+}
+
+// ---------------------------------------------------------------------------
+// legacy drop-in (cuda_funcs.h:33)
+// ---------------------------------------------------------------------------
+static std::mutex g_legacy_mutex;
+static psa_context* g_legacy_ctx = nullptr;
+
+static void legacy_die(const char* what)
+{
+    // cuda_funcs.cu:44-48 pattern: message on stderr, exit(EXIT_FAILURE)
+    std::fprintf(stderr, "%s - %s\n", what, psa_last_error());
+    std::exit(EXIT_FAILURE);
+}
+
+double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2_cap,
+                              Mutant* returned_mutant, int first_offset, int last_offset)
+{
+    std::lock_guard<std::mutex> lock(g_legacy_mutex);
+    const char* base = static_cast<const char*>(cpu_data);
+    int is_max;
+    double weights[4];
+    std::memcpy(&is_max, base, sizeof is_max);
+    std::memcpy(weights, base + 8, sizeof weights);
+    const char* seq1 = base + 40;
+    const char* seq2 = base + 40 + seq1_cap;
+    const int n = (int)strnlen(seq1, seq1_cap);
+    const int m = (int)strnlen(seq2, seq2_cap);
+
+    returned_mutant->offset = -1;          // cuda_funcs.cu:158-160
+    returned_mutant->char_offset = -1;
+    returned_mutant->ch = PSA_NO_CHAR;
+    const double none = is_max ? -INFINITY : INFINITY;
+    if (m < 1 || last_offset <= first_offset) return none;
+
+    if (!g_legacy_ctx) {
+        int device = 0;
+        if (const char* d = std::getenv("PSA_DEVICE")) device = std::atoi(d);
+        if (psa_create(device, nullptr, &g_legacy_ctx) != PSA_OK) legacy_die("Failed to initialise the device context");
+    }
+    psa_context* c = g_legacy_ctx;
+    if (psa_set_weights(c, weights, is_max) != PSA_OK) legacy_die("Failed to build the score tables");
+    if (psa_set_seq1(c, seq1, n) != PSA_OK) legacy_die("Failed to copy data from host to device (seq1)");
+    if (psa_set_seq2(c, seq2, m) != PSA_OK) legacy_die("Failed to copy data from host to device (seq2)");
+    psa_result r;
+    if (psa_search(c, first_offset, last_offset, &r) != PSA_OK) legacy_die("Failed to run the search");
+    if (r.offset < 0 || r.ch == 0) return none;   // cuda_funcs.cu:143-144
+    returned_mutant->offset = r.offset;
+    returned_mutant->char_offset = r.char_offset;
+    returned_mutant->ch = (char)r.ch;
+    return r.score;
+}
+
+double gpu_run_program(const ProgramData* cpu_data, Mutant* returned_mutant, int first_offset, int last_offset)
+{
+    return gpu_run_program_layout(cpu_data, PSA_SEQ1_MAX_LEN, PSA_SEQ2_MAX_LEN, returned_mutant,
+                                  first_offset, last_offset);
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// psa_internal.hpp — shared declarations between the host-side table builder
+// (psa_host.cpp) and the device side (psa_device.hip).  Not installed.
+#pragma once
+
+#include <cstdint>
+#include <string>
+
+#include "psa.h"
+
+namespace psa {
+
+// Symbol codes used on the device: 'A'..'Z' -> 0..25, '-' -> 26,
+// 27 = padding (scores +0.0, never the best substitution), 255 = invalid.
+constexpr int kCodeHyphen = 26;
+constexpr int kCodePad    = 27;
+constexpr int kCodeBad    = 255;
+constexpr int kRow        = 32;   // row stride of every [c2][c1] table
+constexpr int kMaxRanks   = 16;   // distinct substitution deltas incl. rank 0 = "no substitution"
+
+inline int encode_symbol(unsigned char c)
+{
+    if (c >= 'A' && c <= 'Z') return c - 'A';
+    if (c == '-') return kCodeHyphen;
+    return kCodeBad;
+}
+
+// Everything the kernels need that depends only on (weights, is_max).
+// Device tables are indexed [c2][c1] (row = the wave-uniform Seq2 symbol,
+// column = the per-lane Seq1 symbol).
+struct Tables {
+    double        pair[kRow * kRow];     // P: pair score, +0.0 for padding
+    unsigned char rank[kRow * kRow];     // 0 = no substitution, else 1..nranks; higher = better
+    unsigned char sub[kRow * kRow];      // substituted character (ASCII), 0 = none
+    unsigned char cls[kRow * kRow];      // sign class: 0 '*', 1 ':', 2 '.', 3 '_', 4 padding
+    double        delta_of_rank[kMaxRanks];  // delta value of each rank; [0] = -INF (max) / +INF (min)
+    int           nranks;                // number of real ranks
+    // best / worst delta reachable inside each sign class (filter bounds)
+    double        class_best_delta[4];
+    double        class_worst_delta[4];
+    double        weights[4];
+    int           is_max;
+};
+
+// Builds Tables from the reference's rules.  Returns false (and sets err)
+// when a weight is not finite.
+bool build_tables(const double weights[4], int is_max, Tables* out, std::string* err);
+
+// sign of a pair of codes (0..26): get_hashtable_sign, cuda_funcs.cu:424-439
+char sign_of(int c1, int c2);
+
+void set_last_error(const std::string& msg);
+
+}  // namespace psa

@@ -1,0 +1,106 @@
+/*
+ * psa_main.c — the drop-in program: same files, arguments and stdout lines as
+ * the reference's mpiCudaOpenMP binary, with the search done on the MI355X
+ * through gpu_run_program (include/psa.h).
+ *
+ * Mirrors main.c:13-56 and initiate_program, cpu_funcs.c:25-121:
+ *   reads ./input.txt  ("%lf %lf %lf %lf" weights, seq1, seq2, maximum|minimum;
+ *                       cpu_funcs.c:353-368),
+ *   writes ./output.txt ("<mutated seq2>\n<offset> <score %g>", no trailing
+ *                       newline; cpu_funcs.c:96-98, 373-378),
+ *   prints the three stdout lines (cpu_funcs.c:55,153, main.c:47),
+ *   exit code 2 on I/O errors (MPI_Abort(..., 2), cpu_funcs.c:38,44,104,110).
+ * argv[1] (CUDA percentage, main.c:30-42) is accepted; every offset runs on
+ * the GPU here (there is no CPU search path in this program), so the value
+ * only changes the printed line when it is a valid percentage.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "psa.h"
+
+static int read_token(FILE* f, char* dst, size_t cap)
+{
+    size_t len = 0;
+    int c;
+    do { c = fgetc(f); } while (c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v');
+    if (c == EOF) return 0;
+    while (c != EOF && c != ' ' && c != '\t' && c != '\n' && c != '\r' && c != '\f' && c != '\v') {
+        if (len + 1 >= cap) return -1;   /* longer than the struct's array: the reference overflows here */
+        dst[len++] = (char)c;
+        c = fgetc(f);
+    }
+    dst[len] = '\0';
+    return 1;
+}
+
+static ProgramData g_data;   /* ~1 MB: kept off the stack */
+
+int main(int argc, char* argv[])
+{
+    FILE* in;
+    FILE* out;
+    char word[16];
+    int cuda_percentage = 100;
+    int total_offsets;
+    Mutant mutant;
+    double score;
+    struct timespec t0, t1;
+    static char mut[PSA_SEQ2_MAX_LEN];
+
+    if (argc == 2) {
+        int v = atoi(argv[1]);
+        if (v >= 0 && v <= 100) cuda_percentage = v;
+    }
+
+    in = fopen(PSA_INPUT_FILE, "r");
+    if (!in) {
+        printf("Error open input file `%s`\n", PSA_INPUT_FILE);
+        return 2;
+    }
+    if (fscanf(in, "%lf %lf %lf %lf", &g_data.weights[0], &g_data.weights[1], &g_data.weights[2],
+               &g_data.weights[3]) != 4 ||
+        read_token(in, g_data.seq1, sizeof g_data.seq1) != 1 ||
+        read_token(in, g_data.seq2, sizeof g_data.seq2) != 1 ||
+        read_token(in, word, sizeof word) != 1) {
+        printf("Error reading input file `%s`\n", PSA_INPUT_FILE);
+        fclose(in);
+        return 2;
+    }
+    fclose(in);
+    g_data.is_max = strcmp(word, PSA_MAXIMUM_STR) == 0 ? 1 : 0;
+
+    total_offsets = (int)strlen(g_data.seq1) - (int)strlen(g_data.seq2) + 1;
+    if (total_offsets < 1 || g_data.seq2[0] == '\0') {
+        printf("Error reading input file `%s`\n", PSA_INPUT_FILE);   /* n < m is undefined in the reference */
+        return 2;
+    }
+
+    printf("threads=%2d, processes=%2d\n", 1, 1);
+    printf("CUDA percentage set to %d\n", cuda_percentage);
+
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    score = gpu_run_program(&g_data, &mutant, 0, total_offsets);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+
+    strcpy(mut, g_data.seq2);
+    if (mutant.char_offset >= 0) mut[mutant.char_offset] = mutant.ch;
+
+    out = fopen(PSA_OUTPUT_FILE, "w");
+    if (!out) {
+        printf("Error open or write to the output file %s\n", PSA_OUTPUT_FILE);
+        return 2;
+    }
+    if (fprintf(out, "%s\n%d %g", mut, mutant.offset, score) <= 0) {
+        printf("Error write to the output file %s\n", PSA_OUTPUT_FILE);
+        fclose(out);
+        return 2;
+    }
+    fclose(out);
+
+    printf("total time: %g\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+    return 0;
+}

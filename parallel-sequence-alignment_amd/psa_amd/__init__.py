@@ -1,0 +1,258 @@
+"""ctypes binding of libpsa_amd.so (the C ABI declared in include/psa.h).
+
+This is plumbing only: every search runs in the hand-written HIP kernels
+behind the C ABI.  There is no Python or CPU implementation of the search in
+this package; if the shared library is missing, importing fails, and if no
+HIP device is usable every compute call raises PsaError(PSA_ERR_DEVICE).
+
+Reference interface mirrored here (GuyKabiri/Parallel-Sequence-Alignment):
+  gpu_run_program(ProgramData*, Mutant*, first, last)   cuda_funcs.h:33
+  ProgramData / Mutant                                  program_data.h:6-11, mutant.h:6-10
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsa_amd.so")
+
+PSA_OK, PSA_ERR_ARG, PSA_ERR_ALPHABET, PSA_ERR_DEVICE, PSA_ERR_STATE = range(5)
+ENGINE_AUTO, ENGINE_SEQUENTIAL, ENGINE_FILTER = 0, 1, 2
+
+# every symbol include/psa.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = (
+    "gpu_run_program", "gpu_run_program_layout",
+    "psa_create", "psa_destroy", "psa_set_weights",
+    "psa_set_seq1", "psa_set_seq2", "psa_set_seq1_device", "psa_set_seq2_device",
+    "psa_set_engine", "psa_search", "psa_search_async", "psa_search_wait", "psa_scores",
+    "psa_fold", "psa_shard_range", "psa_build_tables",
+    "psa_set_profiling", "psa_last_timing", "psa_profile_totals",
+    "psa_generate_sequence", "psa_last_error", "psa_version",
+)
+
+
+class PsaError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"psa status {status}: {message}")
+        self.status = status
+
+
+class Result(C.Structure):
+    """psa_result (include/psa.h) — 32 bytes."""
+    _fields_ = [("score", C.c_double), ("offset", C.c_int32), ("char_offset", C.c_int32),
+                ("ch", C.c_int32), ("shard", C.c_int32), ("pairs", C.c_int64)]
+
+    def as_tuple(self):
+        return (self.score, self.offset, self.char_offset, chr(self.ch) if self.ch else "")
+
+
+class Mutant(C.Structure):
+    """Mutant (mutant.h:6-10)."""
+    _fields_ = [("offset", C.c_int), ("char_offset", C.c_int), ("ch", C.c_char)]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no fallback implementation.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i, d = C.c_void_p, C.c_int, C.c_double
+    dp = C.POINTER(C.c_double)
+    lib.psa_last_error.restype = C.c_char_p
+    lib.psa_version.restype = C.c_char_p
+    lib.psa_create.argtypes = [i, vp, C.POINTER(vp)]
+    lib.psa_destroy.argtypes = [vp]
+    lib.psa_destroy.restype = None
+    lib.psa_set_weights.argtypes = [vp, dp, i]
+    lib.psa_set_seq1.argtypes = [vp, C.c_char_p, i]
+    lib.psa_set_seq2.argtypes = [vp, C.c_char_p, i]
+    lib.psa_set_seq1_device.argtypes = [vp, vp, i]
+    lib.psa_set_seq2_device.argtypes = [vp, vp, i]
+    lib.psa_set_engine.argtypes = [vp, i]
+    lib.psa_search.argtypes = [vp, i, i, C.POINTER(Result)]
+    lib.psa_search_async.argtypes = [vp, i, i]
+    lib.psa_search_wait.argtypes = [vp, C.POINTER(Result)]
+    lib.psa_scores.argtypes = [vp, i, i, vp, vp, vp]
+    lib.psa_fold.argtypes = [C.POINTER(Result), i, i, C.POINTER(Result)]
+    lib.psa_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
+    lib.psa_shard_range.restype = None
+    lib.psa_build_tables.argtypes = [dp, i, vp, vp, vp, vp]
+    lib.psa_set_profiling.argtypes = [vp, i]
+    lib.psa_last_timing.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_char_p)]
+    lib.psa_profile_totals.argtypes = [vp, dp, dp, C.POINTER(i)]
+    lib.psa_generate_sequence.argtypes = [C.c_uint64, i, C.c_char_p]
+    lib.psa_generate_sequence.restype = None
+    lib.gpu_run_program.argtypes = [vp, C.POINTER(Mutant), i, i]
+    lib.gpu_run_program.restype = d
+    lib.gpu_run_program_layout.argtypes = [vp, C.c_size_t, C.c_size_t, C.POINTER(Mutant), i, i]
+    lib.gpu_run_program_layout.restype = d
+    return lib
+
+
+lib = _load()
+
+
+def _check(status: int) -> None:
+    if status != PSA_OK:
+        raise PsaError(status, lib.psa_last_error().decode())
+
+
+def _weights(w: Sequence[float]):
+    if len(w) != 4:
+        raise ValueError("weights must have 4 entries (w1..w4, def.h:12-15)")
+    return (C.c_double * 4)(*[float(x) for x in w])
+
+
+def version() -> str:
+    return lib.psa_version().decode()
+
+
+def generate_sequence(seed: int, n: int) -> bytes:
+    """Uniform A..Z letters from the library's counter-based SplitMix64 stream."""
+    buf = C.create_string_buffer(n + 1)
+    lib.psa_generate_sequence(C.c_uint64(seed & (2**64 - 1)), n, buf)
+    return buf.raw[:n]
+
+
+def generate_sequence_np(seed: int, n: int) -> np.ndarray:
+    """Same stream as generate_sequence, vectorised (uint8 array of ASCII codes)."""
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & (2**64 - 1)) + (np.arange(n, dtype=np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z ^= z >> np.uint64(31)
+        return (np.uint64(65) + (((z >> np.uint64(32)) * np.uint64(26)) >> np.uint64(32))).astype(np.uint8)
+
+
+@dataclass
+class Tables:
+    P: np.ndarray      # [32,32] float64, index [c1][c2]
+    SUB: np.ndarray    # [32,32] uint8 (ASCII, 0 = none)
+    DELTA: np.ndarray  # [32,32] float64
+    SIGN: np.ndarray   # [32,32] uint8 (ASCII sign, 0 = padding)
+
+
+def build_tables(weights: Sequence[float], is_max: bool) -> Tables:
+    P = np.zeros((32, 32), np.float64)
+    SUB = np.zeros((32, 32), np.uint8)
+    DELTA = np.zeros((32, 32), np.float64)
+    SIGN = np.zeros((32, 32), np.uint8)
+    _check(lib.psa_build_tables(_weights(weights), int(bool(is_max)), P.ctypes.data, SUB.ctypes.data,
+                                DELTA.ctypes.data, SIGN.ctypes.data))
+    return Tables(P, SUB, DELTA, SIGN)
+
+
+def shard_range(total_offsets: int, nshards: int, rank: int):
+    lo, hi = C.c_int(), C.c_int()
+    lib.psa_shard_range(total_offsets, nshards, rank, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def fold(records: Sequence[Result], is_max: bool) -> Result:
+    arr = (Result * len(records))(*records)
+    out = Result()
+    _check(lib.psa_fold(arr, len(records), int(bool(is_max)), C.byref(out)))
+    return out
+
+
+class Context:
+    """Persistent device context (psa_create .. psa_destroy)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self._h = C.c_void_p()
+        _check(lib.psa_create(device, C.c_void_p(stream or 0), C.byref(self._h)))
+        self.n = self.m = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib.psa_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def set_weights(self, weights: Sequence[float], is_max: bool):
+        _check(lib.psa_set_weights(self._h, _weights(weights), int(bool(is_max))))
+
+    def set_seq1(self, seq1: bytes):
+        _check(lib.psa_set_seq1(self._h, seq1, len(seq1)))
+        self.n = len(seq1)
+
+    def set_seq2(self, seq2: bytes):
+        _check(lib.psa_set_seq2(self._h, seq2, len(seq2)))
+        self.m = len(seq2)
+
+    def set_seq1_device(self, ptr: int, n: int):
+        _check(lib.psa_set_seq1_device(self._h, C.c_void_p(ptr), n))
+        self.n = n
+
+    def set_seq2_device(self, ptr: int, m: int):
+        _check(lib.psa_set_seq2_device(self._h, C.c_void_p(ptr), m))
+        self.m = m
+
+    def set_engine(self, engine: int):
+        _check(lib.psa_set_engine(self._h, engine))
+
+    def total_offsets(self) -> int:
+        return self.n - self.m + 1
+
+    def search(self, first: Optional[int] = None, last: Optional[int] = None) -> Result:
+        first = 0 if first is None else first
+        last = self.total_offsets() if last is None else last
+        out = Result()
+        _check(lib.psa_search(self._h, first, last, C.byref(out)))
+        return out
+
+    def search_async(self, first: int, last: int):
+        _check(lib.psa_search_async(self._h, first, last))
+
+    def search_wait(self) -> Result:
+        out = Result()
+        _check(lib.psa_search_wait(self._h, C.byref(out)))
+        return out
+
+    def scores(self, first: Optional[int] = None, last: Optional[int] = None):
+        first = 0 if first is None else first
+        last = self.total_offsets() if last is None else last
+        span = last - first
+        s = np.empty(span, np.float64)
+        ci = np.empty(span, np.int32)
+        ch = np.empty(span, np.int32)
+        _check(lib.psa_scores(self._h, first, last, s.ctypes.data, ci.ctypes.data, ch.ctypes.data))
+        return s, ci, ch
+
+    def set_profiling(self, on: bool):
+        _check(lib.psa_set_profiling(self._h, int(on)))
+
+    def last_timing(self, which: int):
+        ms = C.c_float()
+        name = C.c_char_p()
+        _check(lib.psa_last_timing(self._h, which, C.byref(ms), C.byref(name)))
+        return ms.value, (name.value or b"").decode()
+
+    def profile_totals(self):
+        """(sum of search ms, sum of dominant-kernel ms, searches) since set_profiling(True)."""
+        a, b, k = C.c_double(), C.c_double(), C.c_int()
+        _check(lib.psa_profile_totals(self._h, C.byref(a), C.byref(b), C.byref(k)))
+        return a.value, b.value, k.value
+
+
+def search(seq1: bytes, seq2: bytes, weights: Sequence[float], is_max: bool,
+           first: Optional[int] = None, last: Optional[int] = None, device: int = 0) -> Result:
+    """One-shot search on `device` (the body of gpu_run_program)."""
+    with Context(device) as ctx:
+        ctx.set_weights(weights, is_max)
+        ctx.set_seq1(seq1)
+        ctx.set_seq2(seq2)
+        return ctx.search(first, last)

@@ -1,0 +1,44 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "parallel-sequence-alignment_amd")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU oracle (test infrastructure); built with gcc on first use."""
+    from oracle import oracle as orc
+    orc.build()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def psa():
+    """ctypes binding of libpsa_amd.so; built with hipcc if the .so is missing."""
+    lib_path = os.path.join(PKG, "psa_amd", "libpsa_amd.so")
+    if not os.path.exists(lib_path):
+        import __graft_entry__
+        __graft_entry__.build()
+    import psa_amd
+    return psa_amd
+
+
+@pytest.fixture(scope="session")
+def reference_records(oracle):
+    """The 15 stacked records of the reference's input.txt (tests/golden copy)."""
+    return oracle.read_records(os.path.join(GOLDEN, "reference_input.txt"))
+
+
+# distinct records of input.txt (SURVEY.md Appendix B numbering)
+DISTINCT_RECORDS = [0, 1, 4, 5, 7, 8, 9, 10, 11, 13]

@@ -1,0 +1,64 @@
+"""Generates tests/golden/synthetic_golden.json with the CPU oracle.
+
+Run from the repo root:  python tests/golden/make_golden.py [--full]
+Inputs are the library's seeded SplitMix64 sequences (uniform A..Z, the
+distribution of the reference's own generator, main.c:73,81); expected outputs
+are the oracle's (offset, char_offset, ch, score %.17g).  --full adds the
+BASELINE.json full-size cases (1M x 10k; minutes of CPU time).
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "parallel-sequence-alignment_amd"))
+
+from oracle import oracle  # noqa: E402
+import psa_amd  # noqa: E402  (generator only; no GPU needed)
+
+W_README = [1.5, 2.6, 0.3, 0.2]
+CASES = [
+    # name, seed1, seed2, n, m, weights, is_max
+    ("tiny_max", 11, 12, 200, 7, [1, 1, 1, 1], True),
+    ("tiny_min", 11, 12, 200, 7, [1, 3, 4, 2], False),
+    ("small_max", 21, 22, 5000, 100, W_README, True),
+    ("small_min", 21, 22, 5000, 100, W_README, False),
+    ("odd_max", 31, 32, 20011, 257, [0.8, 0.54, 2.6, 13.7], True),
+    ("odd_min", 31, 32, 20011, 257, [0.8, 0.54, 2.6, 13.7], False),
+    ("c2_max", 1001, 2001, 100000, 1000, W_README, True),     # BASELINE.json configs[1]
+    ("c2_min", 1001, 2001, 100000, 1000, W_README, False),
+]
+FULL = [
+    ("c3_max", 1002, 2002, 1000000, 10000, W_README, True),   # BASELINE.json configs[2]
+    ("c3_min", 1002, 2002, 1000000, 10000, W_README, False),
+]
+
+
+def main():
+    out_path = os.path.join(ROOT, "tests", "golden", "synthetic_golden.json")
+    cases = CASES + (FULL if "--full" in sys.argv else [])
+    old = {}
+    if os.path.exists(out_path):
+        old = {c["name"]: c for c in json.load(open(out_path))["cases"]}
+    done = []
+    threads = os.cpu_count() or 1
+    for name, seed1, seed2, n, m, w, is_max in cases:
+        s1 = psa_amd.generate_sequence(seed1, n)
+        s2 = psa_amd.generate_sequence(seed2, m)
+        t0 = time.time()
+        score, off, ci, ch = oracle.search(s1, s2, w, is_max, threads=threads)
+        dt = time.time() - t0
+        done.append(dict(name=name, seed1=seed1, seed2=seed2, n=n, m=m, weights=w, is_max=is_max,
+                         offset=off, char_offset=ci, ch=ch, score="%.17g" % score,
+                         oracle_seconds=round(dt, 3), oracle_threads=threads))
+        print(name, off, ci, ch, "%.17g" % score, f"{dt:.2f}s", flush=True)
+    names = {c["name"] for c in done}
+    done += [c for k, c in old.items() if k not in names]   # keep full-size cases from an earlier --full run
+    json.dump({"_provenance": "tests/golden/make_golden.py (CPU oracle, oracle/psa_oracle.c)", "cases": done},
+              open(out_path, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

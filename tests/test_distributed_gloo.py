@@ -1,0 +1,60 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo runs of the exact exchange+fold
+bench.py uses on RCCL — shard ranges (cpu_funcs.c:128-133), one all-reduce of
+the one-hot record buffer, psa_fold — with per-shard records supplied by the
+oracle (no GPU here).  The folded answer must equal the full-range search."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, case, out):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import psa_amd as psa
+    import bench
+    from oracle import oracle
+    w, s1, s2, is_max = case
+    total = len(s1) - len(s2) + 1
+    lo, hi = psa.shard_range(total, world, rank)
+    score, off, ci, ch = oracle.search(s1, s2, w, is_max, lo, hi, threads=1)
+    rec = psa.Result()
+    rec.score, rec.offset, rec.char_offset, rec.ch, rec.shard, rec.pairs = score, off, ci, ord(ch), rank, (hi - lo) * len(s2)
+    got = bench.exchange_and_fold(psa, dist, torch, rec, rank, world, is_max, torch.device("cpu"))
+    out[rank] = (got.score, got.offset, got.char_offset, chr(got.ch), got.shard, got.pairs)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("rec", [5, 13])   # tie-heavy records: lowest offset (= lowest rank) must win
+def test_shard_exchange_fold(oracle, psa, reference_records, world, rec):
+    w, s1, s2, is_max = reference_records[rec]
+    want = oracle.search(s1, s2, w, is_max, threads=4)
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, _free_port(), (w, s1, s2, is_max), out), nprocs=world, join=True)
+    total = len(s1) - len(s2) + 1
+    for rank in range(world):
+        got = out[rank]
+        assert got[:4] == want
+        lo, hi = psa.shard_range(total, world, got[4])
+        assert lo <= got[1] < hi            # the winning shard is the one that owns the offset
+        assert got[5] == total * len(s2)

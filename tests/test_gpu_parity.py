@@ -1,0 +1,257 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Bar (BASELINE.json north_star): offset, char_offset and substituted character
+bit-exact; score within 1e-6 — the design goes further and requires the score
+to be bit-identical (same fp64 additions in the same order as
+cpu_funcs.c:271-299), which is what these tests assert.
+"""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, DISTINCT_RECORDS
+
+pytestmark = pytest.mark.gpu
+
+W_README = [1.5, 2.6, 0.3, 0.2]
+
+
+@pytest.fixture(scope="module")
+def ctx(psa):
+    with psa.Context(0) as c:
+        yield c
+
+
+def run(ctx, s1, s2, w, is_max, first=None, last=None):
+    ctx.set_weights(w, is_max)
+    ctx.set_seq1(s1)
+    ctx.set_seq2(s2)
+    return ctx.search(first, last)
+
+
+def assert_same(res, want):
+    score, off, ci, ch = want
+    assert (res.offset, res.char_offset, chr(res.ch)) == (off, ci, ch)
+    assert res.score == score          # bit-exact, stronger than the 1e-6 bar
+
+
+@pytest.mark.parametrize("rec", DISTINCT_RECORDS)
+def test_reference_records(ctx, oracle, reference_records, rec):
+    """Every distinct stacked record of the reference's input.txt; record 0 is
+    the one output.txt publishes, record 5 the sequential-rounding trap."""
+    w, s1, s2, is_max = reference_records[rec]
+    res = run(ctx, s1, s2, w, is_max)
+    assert_same(res, oracle.search(s1, s2, w, is_max, threads=8))
+    assert res.pairs == (len(s1) - len(s2) + 1) * len(s2)
+
+
+def test_output_txt(ctx, reference_records):
+    w, s1, s2, is_max = reference_records[0]
+    res = run(ctx, s1, s2, w, is_max)
+    mut = bytearray(s2)
+    mut[res.char_offset] = res.ch
+    text = b"%s\n%d %s" % (bytes(mut), res.offset, ("%g" % res.score).encode())
+    assert text == open(os.path.join(GOLDEN, "reference_output.txt"), "rb").read()
+
+
+def test_survey_known_answers(ctx, reference_records):
+    gold = json.load(open(os.path.join(GOLDEN, "survey_appendix_b.json")))["records"]
+    for g in gold:
+        w, s1, s2, is_max = reference_records[g["rec"]]
+        res = run(ctx, s1, s2, w, is_max)
+        assert (res.offset, res.char_offset, chr(res.ch), "%.17g" % res.score) == \
+               (g["offset"], g["char_offset"], g["new"], g["score"])
+
+
+@pytest.mark.parametrize("rec", [1, 4, 5, 8, 10, 11, 13])
+def test_per_offset_scores_bit_exact(ctx, oracle, reference_records, rec):
+    """find_best_mutant_offset for EVERY offset: score bits, char_offset and ch."""
+    w, s1, s2, is_max = reference_records[rec]
+    ctx.set_weights(w, is_max)
+    ctx.set_seq1(s1)
+    ctx.set_seq2(s2)
+    s, ci, ch = ctx.scores()
+    os_, oci, och = oracle.scores(s1, s2, w, is_max)
+    assert np.array_equal(s.view(np.uint64), os_.view(np.uint64))
+    assert np.array_equal(ci, oci)
+    assert np.array_equal(ch.astype(np.uint8), och)
+
+
+def test_synthetic_golden(ctx, psa):
+    """Committed vectors from tests/golden/make_golden.py, including the
+    BASELINE.json sizes (100k x 1k and 1M x 10k, both modes)."""
+    gold = json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))
+    for case in gold["cases"]:
+        s1 = psa.generate_sequence(case["seed1"], case["n"])
+        s2 = psa.generate_sequence(case["seed2"], case["m"])
+        res = run(ctx, s1, s2, case["weights"], case["is_max"])
+        assert (res.offset, res.char_offset, chr(res.ch), "%.17g" % res.score) == \
+               (case["offset"], case["char_offset"], case["ch"], case["score"]), case["name"]
+
+
+def _adversarial(psa):
+    rng = np.random.default_rng(5)
+    motif = b"HERTHTGEKPYECHQC"
+    yield "homopolymer", b"A" * 3000, b"A" * 129, [1, 1, 1, 1]              # every offset ties
+    yield "homopolymer_frac", b"A" * 3000, b"A" * 129, W_README           # ... with rounding
+    yield "motif_repeat", motif * 150, motif * 9 + b"HER", [0.8, 0.54, 2.6, 13.7]
+    yield "hyphens", bytes(rng.choice(list(b"ACDEFGHIKLMNPQRSTVWY-"), 4000)), \
+        bytes(rng.choice(list(b"ACDEFGHIKLMNPQRSTVWY-"), 61)), W_README
+    yield "all_hyphen_seq2", psa.generate_sequence(3, 500), b"-" * 9, [2, 1.5, 1.1, 1.3]
+    yield "m_equals_1", psa.generate_sequence(4, 777), b"K", [1, 3, 4, 2]
+    yield "n_equals_m", psa.generate_sequence(5, 333), psa.generate_sequence(6, 333), W_README
+    yield "n_minus_m_1", psa.generate_sequence(7, 1025), psa.generate_sequence(8, 1024), [5, 4, 3, 2]
+    yield "zero_weights", psa.generate_sequence(9, 900), psa.generate_sequence(10, 37), [0, 0, 0, 0]
+    yield "two_letters", bytes(rng.choice(list(b"AL"), 5000)), bytes(rng.choice(list(b"AL"), 50)), [1, 1, 1, 1]
+    yield "odd_lengths", psa.generate_sequence(13, 6151), psa.generate_sequence(14, 1023), [0.1, 0.7, 0.3, 0.9]
+
+
+def test_adversarial_inputs_both_modes(ctx, oracle, psa):
+    for name, s1, s2, w in _adversarial(psa):
+        for is_max in (True, False):
+            res = run(ctx, s1, s2, w, is_max)
+            want = oracle.search(s1, s2, w, is_max, threads=8)
+            assert (res.offset, res.char_offset, chr(res.ch)) == want[1:], (name, is_max)
+            assert res.score == want[0], (name, is_max)
+            s, ci, ch = ctx.scores()
+            os_, oci, och = oracle.scores(s1, s2, w, is_max)
+            assert np.array_equal(s.view(np.uint64), os_.view(np.uint64)), (name, is_max)
+            assert np.array_equal(ci, oci) and np.array_equal(ch.astype(np.uint8), och), (name, is_max)
+
+
+def test_sub_ranges_and_shard_fold(ctx, oracle, psa):
+    """[first,last) semantics of gpu_run_program (absolute offsets, cuda_funcs.cu:163)
+    and the multi-shard fold == the full search (cpu_funcs.c:128-133, 71-94)."""
+    s1 = psa.generate_sequence(41, 30011)
+    s2 = psa.generate_sequence(42, 211)
+    total = len(s1) - len(s2) + 1
+    for is_max in (True, False):
+        ctx.set_weights(W_README, is_max)
+        ctx.set_seq1(s1)
+        ctx.set_seq2(s2)
+        full = ctx.search()
+        for first, last in ((0, 1), (1, 2), (3, 1030), (total - 1, total), (12345, 12346), (777, total)):
+            res = ctx.search(first, last)
+            assert_same(res, oracle.search(s1, s2, W_README, is_max, first, last, threads=4))
+        for shards in (2, 3, 8):
+            recs = []
+            for r in range(shards):
+                lo, hi = psa.shard_range(total, shards, r)
+                rec = ctx.search(lo, hi)
+                rec.shard = r
+                recs.append(rec)
+            got = psa.fold(recs, is_max)
+            assert (got.score, got.offset, got.char_offset, got.ch) == \
+                   (full.score, full.offset, full.char_offset, full.ch)
+            assert got.pairs == total * len(s2)
+
+
+@pytest.mark.parametrize("r", [1, 2, 4])
+def test_lane_tile_variants(psa, oracle, reference_records, r, monkeypatch):
+    """The R-offsets-per-lane variants of the sequential kernel agree (PSA_SEQ_R)."""
+    monkeypatch.setenv("PSA_SEQ_R", str(r))
+    w, s1, s2, is_max = reference_records[5]
+    with psa.Context(0) as c:
+        c.set_engine(psa.ENGINE_SEQUENTIAL)
+        res = run(c, s1, s2, w, is_max)
+        assert_same(res, oracle.search(s1, s2, w, is_max, threads=4))
+        s, ci, ch = c.scores(3, 4000)
+        os_, oci, och = oracle.scores(s1, s2, w, is_max, 3, 4000)
+        assert np.array_equal(s.view(np.uint64), os_.view(np.uint64))
+        assert np.array_equal(ci, oci)
+
+
+def test_errors(ctx, psa):
+    ctx.set_weights([1, 1, 1, 1], True)
+    with pytest.raises(psa.PsaError) as e:
+        ctx.set_seq1(b"ABCdEF")
+    assert e.value.status == psa.PSA_ERR_ALPHABET
+    with pytest.raises(psa.PsaError) as e:
+        ctx.set_seq2(b"AB CD")
+    assert e.value.status == psa.PSA_ERR_ALPHABET
+    ctx.set_seq1(b"ABCDEF")
+    ctx.set_seq2(b"ABCDEFG")          # n < m (reference quirk 15: undefined there)
+    with pytest.raises(psa.PsaError) as e:
+        ctx.search(0, 1)
+    assert e.value.status == psa.PSA_ERR_ARG
+    ctx.set_seq2(b"ABC")
+    for first, last in ((-1, 2), (0, 5), (2, 2), (3, 1)):
+        with pytest.raises(psa.PsaError) as e:
+            ctx.search(first, last)
+        assert e.value.status == psa.PSA_ERR_ARG
+    assert ctx.search(0, 4).offset >= 0
+
+
+def test_legacy_gpu_run_program(psa, oracle, reference_records):
+    """The drop-in symbol with the reference's stock ProgramData layout
+    (def.h:35-36: 10001 / 5001; is_max@0, weights@8, seq1@40, seq2@10041, 15048 bytes)."""
+    w, s1, s2, is_max = reference_records[0]
+    buf = bytearray(15048)
+    buf[0:4] = int(is_max).to_bytes(4, "little")
+    buf[8:40] = np.array(w, np.float64).tobytes()
+    buf[40:40 + len(s1)] = s1
+    buf[10041:10041 + len(s2)] = s2
+    data = (C.c_char * len(buf)).from_buffer(buf)
+    m = psa.Mutant()
+    score = psa.lib.gpu_run_program_layout(C.addressof(data), 10001, 5001, C.byref(m), 0, len(s1) - len(s2) + 1)
+    assert (m.offset, m.char_offset, m.ch, score) == (4505, 144, b"E", -4879.0)
+    # a sub-range, as divide_execute_tasks hands it over (cpu_funcs.c:144-146,180)
+    score = psa.lib.gpu_run_program_layout(C.addressof(data), 10001, 5001, C.byref(m), 100, 1500)
+    want = oracle.search(s1, s2, w, is_max, 100, 1500, threads=4)
+    assert (score, m.offset, m.char_offset, m.ch.decode()) == want
+    # empty range -> +INF (min) and {-1,-1,'\0'} (cuda_funcs.cu:143-145, 158-161)
+    score = psa.lib.gpu_run_program_layout(C.addressof(data), 10001, 5001, C.byref(m), 5, 5)
+    assert score == float("inf") and (m.offset, m.char_offset, m.ch) == (-1, -1, b"\0")
+
+
+def test_device_resident_inputs(psa, oracle):
+    """Sequences already in HBM (torch uint8 tensors), search on torch's stream."""
+    import torch
+    s1 = psa.generate_sequence(51, 50000)
+    s2 = psa.generate_sequence(52, 500)
+    t1 = torch.frombuffer(bytearray(s1), dtype=torch.uint8).cuda()
+    t2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
+    with psa.Context(0, torch.cuda.current_stream().cuda_stream) as c:
+        c.set_weights(W_README, True)
+        c.set_seq1_device(t1.data_ptr(), t1.numel())
+        c.set_seq2_device(t2.data_ptr(), t2.numel())
+        res = c.search()
+    assert_same(res, oracle.search(s1, s2, W_README, True, threads=8))
+
+
+def test_full_size_properties(ctx, oracle, psa):
+    """BASELINE.json configs[2] size (1M x 10k) through size-independent properties:
+    a planted exact copy of Seq2 is found (max), the winner's score re-derives on the
+    oracle at that single offset, and an 8-shard fold equals the full search."""
+    n, m = 1_000_000, 10_000
+    s1 = bytearray(psa.generate_sequence(1002, n))
+    s2 = psa.generate_sequence(2002, m)
+    plant = 654_321
+    s1[plant:plant + m] = s2
+    s1 = bytes(s1)
+    ctx.set_weights(W_README, True)
+    ctx.set_seq1(s1)
+    ctx.set_seq2(s2)
+    res = ctx.search()
+    assert res.offset == plant
+    want_score, want_ci, want_ch = oracle.score_offset(s1, s2, W_README, True, plant)
+    assert (res.score, res.char_offset, chr(res.ch)) == (want_score, want_ci, want_ch)
+    total = n - m + 1
+    recs = []
+    for r in range(8):
+        lo, hi = psa.shard_range(total, 8, r)
+        recs.append(ctx.search(lo, hi))
+    got = psa.fold(recs, True)
+    assert (got.score, got.offset, got.char_offset, got.ch) == (res.score, res.offset, res.char_offset, res.ch)
+    # min mode on the same data: winner re-derives on the oracle, and no sampled offset beats it
+    ctx.set_weights(W_README, False)
+    res = ctx.search()
+    want_score, want_ci, want_ch = oracle.score_offset(s1, s2, W_README, False, res.offset)
+    assert (res.score, res.char_offset, chr(res.ch)) == (want_score, want_ci, want_ch)
+    rng = np.random.default_rng(1)
+    for o in rng.integers(0, total, 40):
+        s, _, _ = oracle.score_offset(s1, s2, W_README, False, int(o))
+        assert s > res.score or (s == res.score and o >= res.offset)

@@ -1,0 +1,112 @@
+"""Host-side logic of libpsa_amd (no GPU): table build vs the oracle's
+per-pair functions, the shard split, the fold order, the generator, the ABI."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+WEIGHT_SETS = ([1, 3, 4, 2], [1.5, 2.6, 0.3, 0.2], [0.8, 0.54, 2.6, 13.7], [2, 1.5, 1.1, 1.3],
+               [1, 1, 1, 1], [5, 4, 3, 2], [0, 0, 0, 0], [1e-3, 7.25, 7.25, 0.5])
+SYMBOLS = [chr(ord("A") + k) for k in range(26)] + ["-"]
+
+
+def test_library_exports_every_declared_symbol(psa):
+    header = open(os.path.join(ROOT, "include", "psa.h")).read()
+    declared = set(re.findall(r"^\s*(?:psa_status|double|void|const char\*)\s+(\w+)\s*\(", header, re.M))
+    assert declared == set(psa.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(psa.lib, name), name
+    assert "gfx950" in psa.version()
+
+
+@pytest.mark.parametrize("is_max", [True, False])
+@pytest.mark.parametrize("w", WEIGHT_SETS)
+def test_tables_match_oracle(psa, oracle, w, is_max):
+    """P / SUB / DELTA / SIGN for all 27x27 pairs == the oracle's per-pair evaluation
+    (get_hashtable_sign, get_weight, get_substitute; cpu_funcs.c:277-285)."""
+    t = psa.build_tables(w, is_max)
+    for i, a in enumerate(SYMBOLS):
+        for j, b in enumerate(SYMBOLS):
+            sign = oracle.table_sign(a, b)
+            assert chr(t.SIGN[i, j]) == sign
+            p = oracle.weight(sign, w)
+            assert t.P[i, j] == p
+            sub = oracle.substitute(a, b, w, is_max)
+            assert chr(t.SUB[i, j]) == sub
+            delta = oracle.weight(oracle.table_sign(a, sub), w) - p
+            assert t.DELTA[i, j] == delta
+    assert not t.SIGN[27:, :].any() and not t.P[27:, :].any() and not t.P[:, 27:].any()
+
+
+def test_tables_reject_bad_weights(psa):
+    with pytest.raises(psa.PsaError) as e:
+        psa.build_tables([1, float("nan"), 1, 1], True)
+    assert e.value.status == psa.PSA_ERR_ARG
+
+
+def test_shard_range_is_reference_rule(psa):
+    """cpu_funcs.c:128-133: equal slices, last shard takes the remainder."""
+    for total in (1, 7, 8, 990001, 99001, 7581):
+        for n in (1, 2, 3, 4, 8):
+            ranges = [psa.shard_range(total, n, r) for r in range(n)]
+            per = total // n
+            for r, (lo, hi) in enumerate(ranges):
+                assert lo == per * r
+                assert hi == lo + per + (total % n if r == n - 1 else 0)
+            assert ranges[0][0] == 0 and ranges[-1][1] == total
+
+
+def test_fold_order_matches_is_swapable(psa, oracle):
+    """psa_fold == repeated is_swapable (cuda_funcs.cu:290-307), any arrival order."""
+    rng = np.random.default_rng(7)
+    for is_max in (True, False):
+        for _ in range(200):
+            k = int(rng.integers(1, 9))
+            recs = []
+            for shard in range(k):
+                r = psa.Result()
+                r.score = float(rng.integers(-3, 4))          # many exact ties
+                r.offset = int(rng.integers(0, 6)) if rng.random() > 0.15 else -1
+                r.char_offset = int(rng.integers(0, 4)) if r.offset >= 0 else -1
+                r.ch = ord("A") if r.offset >= 0 else 0
+                r.shard = shard
+                r.pairs = 10
+                recs.append(r)
+            got = psa.fold(recs, is_max)
+            best_s, best_m = (-np.inf if is_max else np.inf), None
+            for r in recs:
+                if r.offset < 0:
+                    continue
+                m2 = oracle.Mutant(r.offset, r.char_offset, b"A")
+                if best_m is None or oracle.lib().orc_is_swapable(C.byref(best_m), C.byref(m2), best_s, r.score, int(is_max)):
+                    best_s, best_m = r.score, m2
+            if best_m is None:
+                assert got.offset == -1 and got.ch == 0
+            else:
+                assert (got.score, got.offset, got.char_offset) == (best_s, best_m.offset, best_m.char_offset)
+            assert got.pairs == 10 * k
+
+
+def test_generator_c_equals_numpy(psa):
+    for seed, n in ((0, 1), (1001, 1000), (1002, 4097), (2**63 + 5, 333)):
+        a = np.frombuffer(psa.generate_sequence(seed, n), np.uint8)
+        b = psa.generate_sequence_np(seed, n)
+        assert np.array_equal(a, b)
+        assert a.min() >= ord("A") and a.max() <= ord("Z")
+    big = psa.generate_sequence_np(1002, 1_000_000)
+    counts = np.bincount(big - 65, minlength=26)
+    assert counts.min() > 37000 and counts.max() < 40000   # uniform over A..Z (main.c:73,81)
+
+
+def test_no_device_fails_loudly(psa):
+    """Without a usable HIP device there is no fallback: psa_create reports PSA_ERR_DEVICE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(psa.PsaError) as e:
+        psa.Context(0)
+    assert e.value.status == psa.PSA_ERR_DEVICE
