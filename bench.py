@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--m", type=int, default=10_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="analysis only: time shard 0 of W on one GPU (no collective); not a headline number")
     args = ap.parse_args()
 
     import torch
@@ -103,6 +105,8 @@ def main():
     t1 = torch.from_numpy(s1).to(device)      # inputs resident in HBM before the timed region
     t2 = torch.from_numpy(s2).to(device)
     first, last = psa.shard_range(total, world, rank)
+    if args.emulate_world > 1 and world == 1:
+        first, last = psa.shard_range(total, args.emulate_world, 0)
 
     stream = torch.cuda.current_stream(device)
     ctx = psa.Context(local_rank, stream.cuda_stream)
@@ -138,7 +142,7 @@ def main():
 
     search_ms, kernel_ms, profiled = ctx.profile_totals()
     _, kernel_name = ctx.last_timing(1)
-    pairs_total = total * m                       # whole job per step, all ranks
+    pairs_total = total * m if args.emulate_world <= 1 else (last - first) * m   # whole job per step, all ranks
     pairs_launch = (last - first) * m             # this rank's dominant-kernel launch
     value = pairs_total * args.steps / elapsed
     kernel_s = kernel_ms / max(profiled, 1) / 1e3

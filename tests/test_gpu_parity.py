@@ -98,14 +98,15 @@ def _adversarial(psa):
     yield "homopolymer", b"A" * 3000, b"A" * 129, [1, 1, 1, 1]              # every offset ties
     yield "homopolymer_frac", b"A" * 3000, b"A" * 129, W_README           # ... with rounding
     yield "motif_repeat", motif * 150, motif * 9 + b"HER", [0.8, 0.54, 2.6, 13.7]
-    yield "hyphens", bytes(rng.choice(list(b"ACDEFGHIKLMNPQRSTVWY-"), 4000)), \
-        bytes(rng.choice(list(b"ACDEFGHIKLMNPQRSTVWY-"), 61)), W_README
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY-", np.uint8)
+    yield "hyphens", rng.choice(alpha, 4000).tobytes(), rng.choice(alpha, 61).tobytes(), W_README
     yield "all_hyphen_seq2", psa.generate_sequence(3, 500), b"-" * 9, [2, 1.5, 1.1, 1.3]
     yield "m_equals_1", psa.generate_sequence(4, 777), b"K", [1, 3, 4, 2]
     yield "n_equals_m", psa.generate_sequence(5, 333), psa.generate_sequence(6, 333), W_README
     yield "n_minus_m_1", psa.generate_sequence(7, 1025), psa.generate_sequence(8, 1024), [5, 4, 3, 2]
     yield "zero_weights", psa.generate_sequence(9, 900), psa.generate_sequence(10, 37), [0, 0, 0, 0]
-    yield "two_letters", bytes(rng.choice(list(b"AL"), 5000)), bytes(rng.choice(list(b"AL"), 50)), [1, 1, 1, 1]
+    two = np.frombuffer(b"AL", np.uint8)
+    yield "two_letters", rng.choice(two, 5000).tobytes(), rng.choice(two, 50).tobytes(), [1, 1, 1, 1]
     yield "odd_lengths", psa.generate_sequence(13, 6151), psa.generate_sequence(14, 1023), [0.1, 0.7, 0.3, 0.9]
 
 
