@@ -110,6 +110,17 @@ psa_status psa_search_wait(psa_context* ctx, psa_result* out);
 psa_status psa_scores(psa_context* ctx, int first_offset, int last_offset,
                       double* scores, int32_t* char_offsets, int32_t* chs);
 
+/* Diagnostics of the filter engine (tests): its exact per-offset class counts
+ * (how many of the m pairs are '*', ':' and '.'), and how many searches of this
+ * context overflowed the candidate list and were redone by the sequential
+ * engine.  Arrays are host memory of last-first entries; any may be NULL. */
+psa_status psa_debug_counts(psa_context* ctx, int first_offset, int last_offset,
+                            uint32_t* n_star, uint32_t* n_colon, uint32_t* n_dot);
+int psa_fallback_count(psa_context* ctx);
+/* The filter engine's exact re-score (total + best delta, cpu_funcs.c:299) of
+ * up to 2048 arbitrary offsets, without the filter in front of it. */
+psa_status psa_debug_rescore(psa_context* ctx, const int32_t* offsets, int count, double* scores);
+
 /* Fold of per-shard records with the reference's merge order
  * (is_swapable, cuda_funcs.cu:290-307: strictly better score, then lower
  * offset, then lower char_offset).  Host-only, no device needed. */

@@ -11,19 +11,21 @@
 // substituted position/character is recovered for the winner alone.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "psa_internal.hpp"
 
 namespace psa {
 
 constexpr int kBlock = 256;
-constexpr int kSeq1Pad = 4096;   // code-27 tail behind Seq1 so tile over-reads stay in bounds
+
 
 struct BlockRec {     // per-block / per-shard arg-best
     double score;
@@ -68,6 +70,10 @@ __device__ __forceinline__ void block_fold(bool is_max, double& s, int& o, int& 
     }
 }
 
+}  // namespace psa
+#include "psa_filter_kernels.hpp"
+namespace psa {
+
 // ---------------------------------------------------------------------------
 // encode kernels: ASCII -> codes (psa_internal.hpp), flag anything else
 // ---------------------------------------------------------------------------
@@ -86,7 +92,7 @@ __global__ void psa_encode_seq1(const unsigned char* __restrict__ raw, int n, un
 }
 
 __global__ void psa_encode_seq2(const unsigned char* __restrict__ raw, int m, unsigned int* __restrict__ rows,
-                                int capacity, int* __restrict__ bad)
+                                unsigned char* __restrict__ bytes, int capacity, int* __restrict__ bad)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= capacity) return;
@@ -97,6 +103,7 @@ __global__ void psa_encode_seq2(const unsigned char* __restrict__ raw, int m, un
         if (code == kCodeBad) { atomicOr(bad, 2); code = kCodePad; }
     }
     rows[i] = (unsigned int)code;
+    bytes[i] = (unsigned char)code;
 }
 
 // ---------------------------------------------------------------------------
@@ -288,6 +295,39 @@ using psa::set_last_error;
         }                                                                                      \
     } while (0)
 
+namespace {
+
+constexpr int kLdsLimit = 160 * 1024;
+constexpr int kCandCap = 2048;        // candidates re-scored per search before falling back
+constexpr int kSeq1Slack = 49152;     // code-27 tail behind Seq1: tile + chunk rounding + staged-window over-read
+constexpr int kSeq2Slack = 32768 + 64;
+
+struct Scalars {                      // small device-side state of one filter search
+    int cand_count;
+    int overflow;
+};
+
+struct FilterPlan {
+    int waves = 0;        // 8 or 16 waves per workgroup
+    int nchunks = 0;      // char chunks (grid.y)
+    int chunk_chars = 0;
+    int wave_chars = 0;
+    int lds_slots = 0;
+    int lds_bytes = 0;
+    int ntiles = 0;       // offset tiles (grid.x)
+};
+
+template <typename T>
+psa_status dev_alloc(T** ptr, size_t count)
+{
+    if (*ptr) PSA_HIP(hipFree(*ptr));
+    *ptr = nullptr;
+    PSA_HIP(hipMalloc(reinterpret_cast<void**>(ptr), sizeof(T) * count));
+    return PSA_OK;
+}
+
+}  // namespace
+
 struct psa_context {
     int         device = 0;
     hipStream_t stream = nullptr;
@@ -299,17 +339,30 @@ struct psa_context {
     int         n_cap = 0, m_cap = 0;        // allocated code capacities
 
     unsigned char* d_raw = nullptr;  size_t raw_cap = 0;   // staging for host sequences
-    unsigned char* d_s1 = nullptr;
-    unsigned int*  d_s2rows = nullptr;
+    unsigned char* d_s1 = nullptr;        // Seq1 codes, code-27 padded to n_cap
+    unsigned int*  d_s2rows = nullptr;    // Seq2 codes as u32 (sequential engine: scalar loads)
+    unsigned char* d_s2bytes = nullptr;   // Seq2 codes as bytes (filter engine)
     double*        d_pair = nullptr;
     unsigned char* d_rank = nullptr;
     unsigned char* d_sub = nullptr;
     double*        d_delta = nullptr;
+    unsigned*      d_letter_masks = nullptr;
+    unsigned char* d_clsrank = nullptr;   // class | rank << 3 per pair (rescore kernel)
     psa::BlockRec* d_blocks = nullptr;  int blocks_cap = 0;
     psa_result*    d_result = nullptr;
     psa_result*    h_result = nullptr;   // pinned
     int*           d_bad = nullptr;
     int*           h_bad = nullptr;      // pinned
+
+    // filter engine
+    uint2*              d_masks = nullptr;   int nslots = 0;   bool masks_valid = false;
+    unsigned long long* d_partial = nullptr; size_t partial_cap = 0;
+    double*             d_upper = nullptr;   size_t upper_cap = 0;
+    Scalars*            d_scal = nullptr;
+    Scalars*            h_scal = nullptr;    // pinned
+    int*                d_cand = nullptr;
+    psa::BlockRec*      d_rec = nullptr;
+    unsigned long long* d_block_best = nullptr;   // [kKeyBlocks]
 
     psa_engine  engine = PSA_ENGINE_AUTO;
     int         forced_r = 0;
@@ -319,8 +372,11 @@ struct psa_context {
     bool        timing_valid = false;
     const char* last_kernel = "";
     bool        pending = false;
+    bool        pending_filter = false;      // the search in flight used the filter engine
+    int         pending_first = 0, pending_last = 0;
     double      sum_search_ms = 0.0, sum_kernel_ms = 0.0;   // over profiled searches since profiling was switched on
     int         profiled = 0;
+    int         fallbacks = 0;               // filter searches that overflowed into the sequential engine
 };
 
 namespace {
@@ -334,60 +390,83 @@ psa_status ensure_device(psa_context* c)
 psa_status upload_tables(psa_context* c)
 {
     const psa::Tables& t = c->tables;
+    // class planes of every Seq2 symbol b over the Seq1 symbols a:
+    // lo = class in {'*' (0), '.' (2)}, hi = class in {':' (1), '.' (2)}
+    unsigned letter[psa::kMaskRows * 2];
+    std::memset(letter, 0, sizeof letter);
+    for (int b = 0; b <= psa::kCodeHyphen; ++b)
+        for (int a = 0; a <= psa::kCodeHyphen; ++a) {
+            const int cls = t.cls[b * psa::kRow + a];
+            if (cls == 0 || cls == 2) letter[b * 2 + 0] |= 1u << a;
+            if (cls == 1 || cls == 2) letter[b * 2 + 1] |= 1u << a;
+        }
     PSA_HIP(hipMemcpyAsync(c->d_pair, t.pair, sizeof t.pair, hipMemcpyHostToDevice, c->stream));
     PSA_HIP(hipMemcpyAsync(c->d_rank, t.rank, sizeof t.rank, hipMemcpyHostToDevice, c->stream));
     PSA_HIP(hipMemcpyAsync(c->d_sub, t.sub, sizeof t.sub, hipMemcpyHostToDevice, c->stream));
     PSA_HIP(hipMemcpyAsync(c->d_delta, t.delta_of_rank, sizeof t.delta_of_rank, hipMemcpyHostToDevice, c->stream));
-    PSA_HIP(hipStreamSynchronize(c->stream));   // host arrays may change right after return
+    unsigned char clsrank[psa::kRow * psa::kRow];
+    for (int k = 0; k < psa::kRow * psa::kRow; ++k) clsrank[k] = (unsigned char)(t.cls[k] | (t.rank[k] << 3));
+    PSA_HIP(hipMemcpyAsync(c->d_letter_masks, letter, sizeof letter, hipMemcpyHostToDevice, c->stream));
+    PSA_HIP(hipMemcpyAsync(c->d_clsrank, clsrank, sizeof clsrank, hipMemcpyHostToDevice, c->stream));
+    PSA_HIP(hipStreamSynchronize(c->stream));   // host arrays go out of scope right after return
     return PSA_OK;
 }
 
-psa_status check_bad(psa_context* c, int bit, const char* what)
+// Reads the encode kernels' flag.  Blocking; used by the host-sequence setters
+// (device-sequence setters defer the check to psa_search_wait).
+psa_status check_bad_now(psa_context* c)
 {
     PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     PSA_HIP(hipStreamSynchronize(c->stream));
-    if (*c->h_bad & bit) {
-        PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
-        set_last_error(std::string(what) + " contains a character outside [A-Z-]");
-        return PSA_ERR_ALPHABET;
-    }
     return PSA_OK;
+}
+
+psa_status report_bad(psa_context* c)
+{
+    const int bad = *c->h_bad;
+    if (!bad) return PSA_OK;
+    PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
+    *c->h_bad = 0;
+    if (bad & 1) c->n = -1;
+    if (bad & 2) c->m = -1;
+    set_last_error(std::string(bad & 1 ? "seq1" : "seq2") + " contains a character outside [A-Z-]");
+    return PSA_ERR_ALPHABET;
 }
 
 psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
 {
-    const int need = n + psa::kSeq1Pad;
+    const int need = (n + kSeq1Slack + 63) & ~63;
     if (need > c->n_cap) {
-        if (c->d_s1) PSA_HIP(hipFree(c->d_s1));
-        c->d_s1 = nullptr;
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_s1), need));
+        psa_status st = dev_alloc(&c->d_s1, (size_t)need);
+        if (st != PSA_OK) return st;
         c->n_cap = need;
+        c->nslots = need / 32;
+        st = dev_alloc(&c->d_masks, (size_t)psa::kMaskRows * c->nslots);
+        if (st != PSA_OK) return st;
     }
     c->n = -1;
+    c->masks_valid = false;
     hipLaunchKernelGGL(psa::psa_encode_seq1, dim3((c->n_cap + 255) / 256), dim3(256), 0, c->stream,
                        static_cast<const unsigned char*>(d_raw), n, c->d_s1, c->n_cap, c->d_bad);
     PSA_HIP(hipGetLastError());
-    psa_status st = check_bad(c, 1, "seq1");
-    if (st != PSA_OK) return st;
     c->n = n;
     return PSA_OK;
 }
 
 psa_status encode_seq2(psa_context* c, const void* d_raw, int m)
 {
-    const int need = ((m + 3) & ~3) + 64;
+    const int need = (m + kSeq2Slack + 63) & ~63;
     if (need > c->m_cap) {
-        if (c->d_s2rows) PSA_HIP(hipFree(c->d_s2rows));
-        c->d_s2rows = nullptr;
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_s2rows), sizeof(unsigned int) * need));
+        psa_status st = dev_alloc(&c->d_s2rows, (size_t)need);
+        if (st != PSA_OK) return st;
+        st = dev_alloc(&c->d_s2bytes, (size_t)need);
+        if (st != PSA_OK) return st;
         c->m_cap = need;
     }
     c->m = -1;
     hipLaunchKernelGGL(psa::psa_encode_seq2, dim3((c->m_cap + 255) / 256), dim3(256), 0, c->stream,
-                       static_cast<const unsigned char*>(d_raw), m, c->d_s2rows, c->m_cap, c->d_bad);
+                       static_cast<const unsigned char*>(d_raw), m, c->d_s2rows, c->d_s2bytes, c->m_cap, c->d_bad);
     PSA_HIP(hipGetLastError());
-    psa_status st = check_bad(c, 2, "seq2");
-    if (st != PSA_OK) return st;
     c->m = m;
     return PSA_OK;
 }
@@ -395,21 +474,19 @@ psa_status encode_seq2(psa_context* c, const void* d_raw, int m)
 psa_status stage_host(psa_context* c, const char* host, int len)
 {
     if ((size_t)len > c->raw_cap) {
-        if (c->d_raw) PSA_HIP(hipFree(c->d_raw));
-        c->d_raw = nullptr;
-        c->raw_cap = 0;
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_raw), (size_t)len + 64));
+        psa_status st = dev_alloc(&c->d_raw, (size_t)len + 64);
+        if (st != PSA_OK) { c->raw_cap = 0; return st; }
         c->raw_cap = (size_t)len + 64;
     }
     PSA_HIP(hipMemcpyAsync(c->d_raw, host, len, hipMemcpyHostToDevice, c->stream));
     return PSA_OK;
 }
 
+// ---- sequential engine ---------------------------------------------------------
 int pick_r(const psa_context* c, int span)
 {
     if (c->forced_r == 1 || c->forced_r == 2 || c->forced_r == 4) return c->forced_r;
-    // 1024 SIMDs; keep >= ~3 waves per SIMD before widening the per-lane tile
-    if (span >= 4 * 64 * 3072) return 4;
+    // 1024 SIMDs: keep several waves per SIMD before widening the per-lane tile
     if (span >= 2 * 64 * 3072) return 2;
     return 1;
 }
@@ -422,10 +499,8 @@ psa_status launch_sequential(psa_context* c, int first, int last, double* per_sc
     const int lanes = (last - base + r - 1) / r;
     const int nblocks = (lanes + psa::kBlock - 1) / psa::kBlock;
     if (nblocks > c->blocks_cap) {
-        if (c->d_blocks) PSA_HIP(hipFree(c->d_blocks));
-        c->d_blocks = nullptr;
-        c->blocks_cap = 0;
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_blocks), sizeof(psa::BlockRec) * (size_t)nblocks));
+        psa_status st = dev_alloc(&c->d_blocks, (size_t)nblocks);
+        if (st != PSA_OK) { c->blocks_cap = 0; return st; }
         c->blocks_cap = nblocks;
     }
     psa::SeqArgs a;
@@ -478,6 +553,249 @@ psa_status launch_sequential(psa_context* c, int first, int last, double* per_sc
     return PSA_OK;
 }
 
+// ---- filter engine -------------------------------------------------------------
+int exchange_bytes(int waves)
+{
+    // round 0 of the epilogue: waves/2 writers, 6*kPlanes+2 dwords per lane
+    return (waves / 2) * (2 * psa::kCounters * psa::kPlanes) * 64 * 4;
+}
+
+bool plan_filter(int first, int last, int m, FilterPlan* best)
+{
+    const int ntiles = (last - (first & ~31) + psa::kTile - 1) / psa::kTile;
+    const int publish = psa::kCounters * psa::kMergedPlanes * 128 * 4;
+    double best_cost = 0.0;
+    bool found = false;
+    // experiment knobs (not part of the API): force the workgroup shape / chunk count
+    static const int force_waves = std::getenv("PSA_FILTER_WAVES") ? std::atoi(std::getenv("PSA_FILTER_WAVES")) : 0;
+    static const int force_chunks = std::getenv("PSA_FILTER_CHUNKS") ? std::atoi(std::getenv("PSA_FILTER_CHUNKS")) : 0;
+    for (int waves : {16, 8}) {
+        if (force_waves && waves != force_waves) continue;
+        const int gran = waves * psa::kUnroll;
+        for (int nchunks = 1; nchunks <= 64; ++nchunks) {
+            if (force_chunks && nchunks != force_chunks) continue;
+            int chunk = (m + nchunks - 1) / nchunks;
+            chunk = (chunk + gran - 1) / gran * gran;
+            if ((long long)chunk * (nchunks - 1) >= m && nchunks > 1) continue;   // last chunk would be empty
+            const int wave_chars = chunk / waves;
+            if (wave_chars > psa::kMaxWaveChars) continue;
+            const int slots = chunk / 32 + 129;
+            int lds = psa::kMaskRows * slots * 8;
+            if (exchange_bytes(waves) > lds) lds = exchange_bytes(waves);
+            if (publish > lds) lds = publish;
+            if (lds > kLdsLimit) continue;
+            // the count kernel needs ~120 VGPRs: 16 waves per CU
+            int per_cu = kLdsLimit / lds;
+            if (per_cu > 16 / waves) per_cu = 16 / waves;
+            const long long blocks = (long long)ntiles * nchunks;
+            const long long rounds = (blocks + 256 * per_cu - 1) / (256 * per_cu);   // waves of co-resident workgroups
+            // VALU-bound: ~12.3 CU-cycles per char of a workgroup, plus staging and the epilogue
+            const double block_cost = 12.3 * chunk + 0.5 * psa::kMaskRows * slots + 4000.0;
+            const double cost = (double)rounds * per_cu * block_cost;
+            if (!found || cost < best_cost) {
+                found = true;
+                best_cost = cost;
+                best->waves = waves;
+                best->nchunks = nchunks;
+                best->chunk_chars = chunk;
+                best->wave_chars = wave_chars;
+                best->lds_slots = slots;
+                best->lds_bytes = lds;
+                best->ntiles = ntiles;
+            }
+        }
+    }
+    return found;
+}
+
+psa_status ensure_masks(psa_context* c)
+{
+    if (c->masks_valid) return PSA_OK;
+    psa::MaskArgs a;
+    a.s1 = c->d_s1;
+    a.masks = c->d_masks;
+    a.letter_masks = c->d_letter_masks;
+    a.nslots = c->nslots;
+    hipLaunchKernelGGL(psa::psa_build_masks_kernel, dim3((c->nslots + 255) / 256), dim3(256), 0, c->stream, a);
+    PSA_HIP(hipGetLastError());
+    c->masks_valid = true;
+    return PSA_OK;
+}
+
+double filter_slack(const psa_context* c)
+{
+    // |sequential fp64 sum - exact sum| <= (m-1) u sum|p_i| / (1 - (m-1) u)   (u = 2^-53),
+    // the count formula and the "+ delta" add a handful of roundings more.
+    // Doubled, so that a borderline offset is always re-scored rather than dropped.
+    double wmax = 0.0, dmax = 0.0;
+    for (int k = 0; k < 4; ++k) wmax = std::fmax(wmax, std::fabs(c->tables.weights[k]));
+    for (int r = 1; r <= c->tables.nranks; ++r) dmax = std::fmax(dmax, std::fabs(c->tables.delta_of_rank[r]));
+    const double u = 1.1102230246251565e-16;
+    const double mag = (double)c->m * wmax + dmax;
+    return 2.0 * 1.05 * ((double)c->m + 32.0) * u * mag;
+}
+
+psa_status launch_count(psa_context* c, const FilterPlan& p, int base, int span_pad)
+{
+    psa::CountArgs a;
+    a.masks = c->d_masks;
+    a.s2 = c->d_s2bytes;
+    a.partial = c->d_partial;
+    a.nslots = c->nslots;
+    a.base = base;
+    a.span_pad = span_pad;
+    a.chunk_chars = p.chunk_chars;
+    a.wave_chars = p.wave_chars;
+    a.lds_slots = p.lds_slots;
+    const dim3 grid(p.ntiles, p.nchunks);
+    if (p.waves == 16) {
+        PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_bytes));
+        hipLaunchKernelGGL(psa::psa_count_kernel<16>, grid, dim3(16 * 64), p.lds_bytes, c->stream, a);
+        c->last_kernel = "psa_count_kernel<16>";
+    } else {
+        PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<8>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_bytes));
+        hipLaunchKernelGGL(psa::psa_count_kernel<8>, grid, dim3(8 * 64), p.lds_bytes, c->stream, a);
+        c->last_kernel = "psa_count_kernel<8>";
+    }
+    PSA_HIP(hipGetLastError());
+    return PSA_OK;
+}
+
+psa_status launch_rescore(psa_context* c)
+{
+    const psa::Tables& t = c->tables;
+    psa::RescoreArgs r;
+    r.s1 = c->d_s1;
+    r.s2 = c->d_s2bytes;
+    r.clsrank = c->d_clsrank;
+    r.delta_of_rank = c->d_delta;
+    r.cand = c->d_cand;
+    r.cand_count = &c->d_scal->cand_count;
+    r.rec = c->d_rec;
+    r.class_value[0] = t.weights[0];       // get_weight, cuda_funcs.cu:442-452
+    r.class_value[1] = -t.weights[1];
+    r.class_value[2] = -t.weights[2];
+    r.class_value[3] = -t.weights[3];
+    for (int i = 4; i < 8; ++i) r.class_value[i] = 0.0;
+    r.m = c->m;
+    r.cap = kCandCap;
+    r.is_max = t.is_max;
+    {
+        // the integer walk needs normal (or zero) addends and a running sum at least two
+        // binades above the largest of them
+        int max_exp = 0;
+        bool ok = true;
+        for (int i = 0; i < 4; ++i) {
+            unsigned long long bits;
+            std::memcpy(&bits, &r.class_value[i], sizeof bits);
+            const int e = (int)((bits >> 52) & 0x7ff);
+            if (e == 0 && (bits << 1) != 0) ok = false;          // subnormal weight
+            if (e > max_exp) max_exp = e;
+        }
+        r.fast_ok = ok && std::getenv("PSA_RESCORE_CHAIN") == nullptr;
+        r.fast_min_exp = max_exp + 2;
+    }
+    hipLaunchKernelGGL(psa::psa_rescore_kernel, dim3(kCandCap), dim3(64), 0, c->stream, r);
+    PSA_HIP(hipGetLastError());
+
+    return PSA_OK;
+}
+
+psa_status launch_filter(psa_context* c, int first, int last)
+{
+    const int span = last - first;
+    const int base = first & ~31;
+    FilterPlan p;
+    if (!plan_filter(first, last, c->m, &p)) {
+        set_last_error("internal: no filter plan fits the LDS");
+        return PSA_ERR_ARG;
+    }
+    const int span_pad = p.ntiles * psa::kTile;
+    const size_t need_partial = (size_t)p.nchunks * span_pad;
+    if (need_partial > c->partial_cap) {
+        psa_status st = dev_alloc(&c->d_partial, need_partial);
+        if (st != PSA_OK) { c->partial_cap = 0; return st; }
+        c->partial_cap = need_partial;
+    }
+    if ((size_t)span > c->upper_cap) {
+        psa_status st = dev_alloc(&c->d_upper, (size_t)span);
+        if (st != PSA_OK) { c->upper_cap = 0; return st; }
+        c->upper_cap = (size_t)span;
+    }
+    PSA_HIP(hipMemsetAsync(c->d_scal, 0, sizeof(Scalars), c->stream));
+    psa_status st = ensure_masks(c);
+    if (st != PSA_OK) return st;
+
+    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[2], c->stream));
+    st = launch_count(c, p, base, span_pad);
+    if (st != PSA_OK) return st;
+    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[3], c->stream));
+
+    const psa::Tables& t = c->tables;
+    psa::KeyArgs k;
+    k.partial = c->d_partial;
+    k.upper = c->d_upper;
+    k.block_best = c->d_block_best;
+    for (int i = 0; i < 4; ++i) {
+        k.w[i] = t.weights[i];
+        k.class_best[i] = t.class_best_delta[i];
+        k.class_worst[i] = t.class_worst_delta[i];
+    }
+    k.slack = filter_slack(c);
+    k.nchunks = p.nchunks;
+    k.span_pad = span_pad;
+    k.span = span;
+    k.lead = first - base;
+    k.m = c->m;
+    k.is_max = t.is_max;
+    const int key_blocks = std::min(psa::kKeyBlocks, (span + 255) / 256);
+    hipLaunchKernelGGL(psa::psa_keys_kernel, dim3(key_blocks), dim3(256), 0, c->stream, k);
+    PSA_HIP(hipGetLastError());
+
+    psa::SelectArgs s;
+    s.upper = c->d_upper;
+    s.block_best = c->d_block_best;
+    s.nbest = key_blocks;
+    s.cand = c->d_cand;
+    s.cand_count = &c->d_scal->cand_count;
+    s.span = span;
+    s.first = first;
+    s.cap = kCandCap;
+    hipLaunchKernelGGL(psa::psa_select_kernel, dim3(key_blocks), dim3(256), 0, c->stream, s);
+    PSA_HIP(hipGetLastError());
+
+    psa_status rst = launch_rescore(c);
+    if (rst != PSA_OK) return rst;
+
+    psa::FoldArgs f;
+    f.rec = c->d_rec;
+    f.cand_count = &c->d_scal->cand_count;
+    f.s1 = c->d_s1;
+    f.s2 = c->d_s2bytes;
+    f.rank = c->d_rank;
+    f.sub = c->d_sub;
+    f.out = c->d_result;
+    f.overflow = &c->d_scal->overflow;
+    f.m = c->m;
+    f.cap = kCandCap;
+    f.is_max = t.is_max;
+    f.pairs = (long long)span * (long long)c->m;
+    hipLaunchKernelGGL(psa::psa_fold_kernel, dim3(1), dim3(256), 0, c->stream, f);
+    PSA_HIP(hipGetLastError());
+    PSA_HIP(hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(Scalars), hipMemcpyDeviceToHost, c->stream));
+    return PSA_OK;
+}
+
+bool use_filter(const psa_context* c, int first, int last)
+{
+    if (c->engine == PSA_ENGINE_SEQUENTIAL) return false;
+    if (c->engine == PSA_ENGINE_FILTER) return true;
+    // the filter's fixed cost (mask build + 5 small launches) only pays off on big searches
+    return (long long)(last - first) * c->m >= 20000000ll;
+}
+
 psa_status check_ready(psa_context* c, int first, int last)
 {
     if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
@@ -525,10 +843,19 @@ psa_status psa_create(int device, void* stream, psa_context** out)
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_rank), psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_sub), psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_delta), sizeof(double) * psa::kMaxRanks));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_letter_masks), sizeof(unsigned) * psa::kMaskRows * 2));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_result), sizeof(psa_result)));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bad), sizeof(int)));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scal), sizeof(Scalars)));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_cand), sizeof(int) * kCandCap));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_rec), sizeof(psa::BlockRec) * kCandCap));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_clsrank), psa::kRow * psa::kRow));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_block_best), sizeof(unsigned long long) * psa::kKeyBlocks));
         PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_result), sizeof(psa_result), hipHostMallocDefault));
         PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_bad), sizeof(int), hipHostMallocDefault));
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scal), sizeof(Scalars), hipHostMallocDefault));
+        *c->h_bad = 0;
+        std::memset(c->h_scal, 0, sizeof(Scalars));
         PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
         for (auto& ev : c->ev) PSA_HIP(hipEventCreate(&ev));
         PSA_HIP(hipStreamSynchronize(c->stream));
@@ -548,15 +875,26 @@ void psa_destroy(psa_context* c)
     (void)hipFree(c->d_raw);
     (void)hipFree(c->d_s1);
     (void)hipFree(c->d_s2rows);
+    (void)hipFree(c->d_s2bytes);
     (void)hipFree(c->d_pair);
     (void)hipFree(c->d_rank);
     (void)hipFree(c->d_sub);
     (void)hipFree(c->d_delta);
+    (void)hipFree(c->d_letter_masks);
+    (void)hipFree(c->d_clsrank);
     (void)hipFree(c->d_blocks);
     (void)hipFree(c->d_result);
     (void)hipFree(c->d_bad);
+    (void)hipFree(c->d_masks);
+    (void)hipFree(c->d_partial);
+    (void)hipFree(c->d_upper);
+    (void)hipFree(c->d_scal);
+    (void)hipFree(c->d_cand);
+    (void)hipFree(c->d_rec);
+    (void)hipFree(c->d_block_best);
     if (c->h_result) (void)hipHostFree(c->h_result);
     if (c->h_bad) (void)hipHostFree(c->h_bad);
+    if (c->h_scal) (void)hipHostFree(c->h_scal);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -583,7 +921,7 @@ psa_status psa_set_seq1_device(psa_context* c, const void* d_seq1, int n)
     if (!c || !d_seq1 || n < 1) { set_last_error("psa_set_seq1: bad arguments"); return PSA_ERR_ARG; }
     psa_status st = ensure_device(c);
     if (st != PSA_OK) return st;
-    return encode_seq1(c, d_seq1, n);
+    return encode_seq1(c, d_seq1, n);      // alphabet errors surface at psa_search_wait
 }
 
 psa_status psa_set_seq2_device(psa_context* c, const void* d_seq2, int m)
@@ -601,7 +939,11 @@ psa_status psa_set_seq1(psa_context* c, const char* seq1, int n)
     if (st != PSA_OK) return st;
     st = stage_host(c, seq1, n);
     if (st != PSA_OK) return st;
-    return encode_seq1(c, c->d_raw, n);
+    st = encode_seq1(c, c->d_raw, n);
+    if (st != PSA_OK) return st;
+    st = check_bad_now(c);
+    if (st != PSA_OK) return st;
+    return report_bad(c);
 }
 
 psa_status psa_set_seq2(psa_context* c, const char* seq2, int m)
@@ -611,7 +953,11 @@ psa_status psa_set_seq2(psa_context* c, const char* seq2, int m)
     if (st != PSA_OK) return st;
     st = stage_host(c, seq2, m);
     if (st != PSA_OK) return st;
-    return encode_seq2(c, c->d_raw, m);
+    st = encode_seq2(c, c->d_raw, m);
+    if (st != PSA_OK) return st;
+    st = check_bad_now(c);
+    if (st != PSA_OK) return st;
+    return report_bad(c);
 }
 
 psa_status psa_set_engine(psa_context* c, psa_engine engine)
@@ -629,9 +975,13 @@ psa_status psa_search_async(psa_context* c, int first, int last)
     if (st != PSA_OK) return st;
     c->timing_valid = false;
     if (c->profiling) PSA_HIP(hipEventRecord(c->ev[0], c->stream));
-    st = launch_sequential(c, first, last, nullptr, nullptr);
+    c->pending_filter = use_filter(c, first, last);
+    c->pending_first = first;
+    c->pending_last = last;
+    st = c->pending_filter ? launch_filter(c, first, last) : launch_sequential(c, first, last, nullptr, nullptr);
     if (st != PSA_OK) return st;
     PSA_HIP(hipMemcpyAsync(c->h_result, c->d_result, sizeof(psa_result), hipMemcpyDeviceToHost, c->stream));
+    PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (c->profiling) {
         PSA_HIP(hipEventRecord(c->ev[1], c->stream));
         c->timing_valid = true;
@@ -646,6 +996,18 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
     if (!c->pending) { set_last_error("psa_search_wait: no search in flight"); return PSA_ERR_STATE; }
     PSA_HIP(hipStreamSynchronize(c->stream));
     c->pending = false;
+    psa_status st = report_bad(c);            // device-resident sequences are validated here
+    if (st != PSA_OK) return st;
+    if (c->pending_filter && c->h_scal->overflow) {
+        // more near-tied offsets than the candidate list holds (e.g. a homopolymer):
+        // score every offset in reference order instead
+        c->fallbacks += 1;
+        st = launch_sequential(c, c->pending_first, c->pending_last, nullptr, nullptr);
+        if (st != PSA_OK) return st;
+        PSA_HIP(hipMemcpyAsync(c->h_result, c->d_result, sizeof(psa_result), hipMemcpyDeviceToHost, c->stream));
+        PSA_HIP(hipStreamSynchronize(c->stream));
+        c->timing_valid = false;
+    }
     *out = *c->h_result;
     if (c->profiling && c->timing_valid) {
         float a = 0.f, b = 0.f;
@@ -689,14 +1051,90 @@ psa_status psa_scores(psa_context* c, int first, int last, double* scores, int32
         if (scores) PSA_HIP(hipMemcpyAsync(scores, d_score, sizeof(double) * (size_t)span, hipMemcpyDeviceToHost, c->stream));
         if (char_offsets) PSA_HIP(hipMemcpyAsync(char_offsets, d_ci, sizeof(int) * (size_t)span, hipMemcpyDeviceToHost, c->stream));
         if (chs) PSA_HIP(hipMemcpyAsync(chs, d_ch, sizeof(int) * (size_t)span, hipMemcpyDeviceToHost, c->stream));
+        PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
         PSA_HIP(hipStreamSynchronize(c->stream));
-        return PSA_OK;
+        return report_bad(c);
     }();
     (void)hipFree(d_score);
     (void)hipFree(d_prank);
     (void)hipFree(d_ci);
     (void)hipFree(d_ch);
     return st;
+}
+
+// Diagnostic view of the filter engine's exact class counts: n_star / n_colon /
+// n_dot of every offset in [first,last).
+psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_star, uint32_t* n_colon,
+                            uint32_t* n_dot)
+{
+    psa_status st = check_ready(c, first, last);
+    if (st != PSA_OK) return st;
+    st = ensure_device(c);
+    if (st != PSA_OK) return st;
+    const int span = last - first;
+    const int base = first & ~31;
+    const int lead = first - base;
+    FilterPlan p;
+    if (!plan_filter(first, last, c->m, &p)) { set_last_error("internal: no filter plan"); return PSA_ERR_ARG; }
+    const int span_pad = p.ntiles * psa::kTile;
+    const size_t need = (size_t)p.nchunks * span_pad;
+    if (need > c->partial_cap) {
+        st = dev_alloc(&c->d_partial, need);
+        if (st != PSA_OK) { c->partial_cap = 0; return st; }
+        c->partial_cap = need;
+    }
+    st = ensure_masks(c);
+    if (st != PSA_OK) return st;
+    st = launch_count(c, p, base, span_pad);
+    if (st != PSA_OK) return st;
+    std::vector<unsigned long long> host(need);
+    PSA_HIP(hipMemcpyAsync(host.data(), c->d_partial, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PSA_HIP(hipStreamSynchronize(c->stream));
+    st = report_bad(c);
+    if (st != PSA_OK) return st;
+    for (int o = 0; o < span; ++o) {
+        unsigned long long sum = 0;
+        for (int k = 0; k < p.nchunks; ++k) sum += host[(size_t)k * span_pad + lead + o];
+        const uint32_t n_lo = (uint32_t)(sum & 0x1fffff), n_hi = (uint32_t)((sum >> 21) & 0x1fffff);
+        const uint32_t n_both = (uint32_t)((sum >> 42) & 0x1fffff);
+        if (n_star) n_star[o] = n_lo - n_both;
+        if (n_colon) n_colon[o] = n_hi - n_both;
+        if (n_dot) n_dot[o] = n_both;
+    }
+    return PSA_OK;
+}
+
+// Diagnostic: the filter engine's exact re-score of arbitrary offsets
+// (find_best_mutant_offset's return value, cpu_funcs.c:299) without the filter.
+psa_status psa_debug_rescore(psa_context* c, const int32_t* offsets, int count, double* scores)
+{
+    if (!c || !offsets || !scores || count < 1 || count > kCandCap) {
+        set_last_error("psa_debug_rescore: bad arguments (1 <= count <= 2048)");
+        return PSA_ERR_ARG;
+    }
+    psa_status st = check_ready(c, 0, 1);
+    if (st != PSA_OK) return st;
+    st = ensure_device(c);
+    if (st != PSA_OK) return st;
+    const int total = c->n - c->m + 1;
+    for (int k = 0; k < count; ++k)
+        if (offsets[k] < 0 || offsets[k] >= total) { set_last_error("psa_debug_rescore: offset out of range"); return PSA_ERR_ARG; }
+    Scalars sc;
+    sc.cand_count = count;
+    sc.overflow = 0;
+    PSA_HIP(hipMemcpyAsync(c->d_scal, &sc, sizeof sc, hipMemcpyHostToDevice, c->stream));
+    PSA_HIP(hipMemcpyAsync(c->d_cand, offsets, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    st = launch_rescore(c);
+    if (st != PSA_OK) return st;
+    std::vector<psa::BlockRec> host((size_t)count);
+    PSA_HIP(hipMemcpyAsync(host.data(), c->d_rec, sizeof(psa::BlockRec) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PSA_HIP(hipStreamSynchronize(c->stream));
+    st = report_bad(c);
+    if (st != PSA_OK) return st;
+    for (int k = 0; k < count; ++k) scores[k] = host[(size_t)k].score;
+    return PSA_OK;
 }
 
 psa_status psa_set_profiling(psa_context* c, int on)
@@ -728,6 +1166,10 @@ psa_status psa_last_timing(psa_context* c, int which, float* ms, const char** ke
     if (kernel_name) *kernel_name = c->last_kernel;
     return PSA_OK;
 }
+
+// How many filter searches of this context overflowed the candidate list and
+// were redone by the sequential engine (tests; adversarial inputs only).
+int psa_fallback_count(psa_context* c) { return c ? c->fallbacks : 0; }
 
 // ---------------------------------------------------------------------------
 // legacy drop-in (cuda_funcs.h:33)

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "psa_create", "psa_destroy", "psa_set_weights",
     "psa_set_seq1", "psa_set_seq2", "psa_set_seq1_device", "psa_set_seq2_device",
     "psa_set_engine", "psa_search", "psa_search_async", "psa_search_wait", "psa_scores",
+    "psa_debug_counts", "psa_fallback_count", "psa_debug_rescore",
     "psa_fold", "psa_shard_range", "psa_build_tables",
     "psa_set_profiling", "psa_last_timing", "psa_profile_totals",
     "psa_generate_sequence", "psa_last_error", "psa_version",
@@ -79,6 +80,9 @@ def _load() -> C.CDLL:
     lib.psa_search_async.argtypes = [vp, i, i]
     lib.psa_search_wait.argtypes = [vp, C.POINTER(Result)]
     lib.psa_scores.argtypes = [vp, i, i, vp, vp, vp]
+    lib.psa_debug_counts.argtypes = [vp, i, i, vp, vp, vp]
+    lib.psa_fallback_count.argtypes = [vp]
+    lib.psa_debug_rescore.argtypes = [vp, vp, i, vp]
     lib.psa_fold.argtypes = [C.POINTER(Result), i, i, C.POINTER(Result)]
     lib.psa_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.psa_shard_range.restype = None
@@ -231,6 +235,25 @@ class Context:
         ch = np.empty(span, np.int32)
         _check(lib.psa_scores(self._h, first, last, s.ctypes.data, ci.ctypes.data, ch.ctypes.data))
         return s, ci, ch
+
+    def debug_counts(self, first: Optional[int] = None, last: Optional[int] = None):
+        """Filter engine's exact (n_star, n_colon, n_dot) per offset."""
+        first = 0 if first is None else first
+        last = self.total_offsets() if last is None else last
+        span = last - first
+        a, b, c = (np.empty(span, np.uint32) for _ in range(3))
+        _check(lib.psa_debug_counts(self._h, first, last, a.ctypes.data, b.ctypes.data, c.ctypes.data))
+        return a, b, c
+
+    def debug_rescore(self, offsets) -> np.ndarray:
+        """Exact re-score of the given offsets (filter engine's rescore kernel)."""
+        offs = np.ascontiguousarray(offsets, np.int32)
+        out = np.empty(len(offs), np.float64)
+        _check(lib.psa_debug_rescore(self._h, offs.ctypes.data, len(offs), out.ctypes.data))
+        return out
+
+    def fallback_count(self) -> int:
+        return lib.psa_fallback_count(self._h)
 
     def set_profiling(self, on: bool):
         _check(lib.psa_set_profiling(self._h, int(on)))

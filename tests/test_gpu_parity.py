@@ -256,3 +256,140 @@ def test_full_size_properties(ctx, oracle, psa):
     for o in rng.integers(0, total, 40):
         s, _, _ = oracle.score_offset(s1, s2, W_README, False, int(o))
         assert s > res.score or (s == res.score and o >= res.offset)
+
+
+# ---------------------------------------------------------------------------
+# filter engine (bit-sliced class counts -> candidates -> sequential re-score)
+# ---------------------------------------------------------------------------
+def _class_counts_numpy(psa, s1, s2, w, is_max, first, last):
+    """n_star/n_colon/n_dot per offset from the 27x27 SIGN table (plain numpy)."""
+    t = psa.build_tables(w, is_max)
+    code = np.full(256, 27, np.int64)
+    code[65:91] = np.arange(26)
+    code[ord("-")] = 26
+    a = code[np.frombuffer(s1, np.uint8)]
+    b = code[np.frombuffer(s2, np.uint8)]
+    sign = t.SIGN[:27, :27]
+    span, m = last - first, len(s2)
+    out = np.zeros((3, span), np.int64)
+    for i in range(m):
+        col = a[first + i:first + i + span]
+        sg = sign[col, b[i]]
+        out[0] += sg == ord("*")
+        out[1] += sg == ord(":")
+        out[2] += sg == ord(".")
+    return out
+
+
+@pytest.mark.parametrize("n,m,first,last", [
+    (9000, 40, 0, None),          # m barely above one round, one tile
+    (9000, 7, 5, 4100),           # m < one round, range not word-aligned, crosses a tile
+    (30000, 1000, 123, 20001),    # several tiles
+    (12000, 2500, 0, None),       # wave chunks > 1 round
+    (70000, 9000, 1, 50000),      # long Seq2: several char chunks
+])
+def test_filter_class_counts_exact(psa, n, m, first, last):
+    s1 = psa.generate_sequence(61, n)
+    s2 = psa.generate_sequence(62, m)
+    last = n - m + 1 if last is None else last
+    for w, is_max in ((W_README, True), ([1, 3, 4, 2], False)):
+        with psa.Context(0) as c:
+            c.set_weights(w, is_max)
+            c.set_seq1(s1)
+            c.set_seq2(s2)
+            got = c.debug_counts(first, last)
+        want = _class_counts_numpy(psa, s1, s2, w, is_max, first, last)
+        for k in range(3):
+            assert np.array_equal(got[k].astype(np.int64), want[k]), (n, m, k)
+
+
+@pytest.mark.parametrize("rec", DISTINCT_RECORDS)
+def test_filter_engine_reference_records(psa, oracle, reference_records, rec):
+    w, s1, s2, is_max = reference_records[rec]
+    with psa.Context(0) as c:
+        c.set_engine(psa.ENGINE_FILTER)
+        res = run(c, s1, s2, w, is_max)
+    assert_same(res, oracle.search(s1, s2, w, is_max, threads=8))
+
+
+def test_filter_engine_adversarial_and_fallback(psa, oracle):
+    """Tie-heavy inputs: the candidate list overflows and the sequential engine takes over
+    (homopolymer: every offset ties); answers stay bit-identical either way."""
+    with psa.Context(0) as c:
+        c.set_engine(psa.ENGINE_FILTER)
+        for name, s1, s2, w in _adversarial(psa):
+            for is_max in (True, False):
+                res = run(c, s1, s2, w, is_max)
+                want = oracle.search(s1, s2, w, is_max, threads=8)
+                assert (res.offset, res.char_offset, chr(res.ch)) == want[1:], (name, is_max)
+                assert res.score == want[0], (name, is_max)
+        assert c.fallback_count() >= 2          # the two homopolymer cases, both modes
+
+
+def test_filter_engine_synthetic_golden_and_ranges(psa, oracle):
+    gold = json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))
+    with psa.Context(0) as c:
+        c.set_engine(psa.ENGINE_FILTER)
+        for case in gold["cases"]:
+            s1 = psa.generate_sequence(case["seed1"], case["n"])
+            s2 = psa.generate_sequence(case["seed2"], case["m"])
+            res = run(c, s1, s2, case["weights"], case["is_max"])
+            assert (res.offset, res.char_offset, chr(res.ch), "%.17g" % res.score) == \
+                   (case["offset"], case["char_offset"], case["ch"], case["score"]), case["name"]
+        assert c.fallback_count() == 0
+        # sub-ranges and shard folds on the last (1M x 10k) case still loaded
+        total = c.total_offsets()
+        full = c.search()
+        recs = []
+        for r in range(8):
+            lo, hi = psa.shard_range(total, 8, r)
+            recs.append(c.search(lo, hi))
+        got = psa.fold(recs, gold["cases"][-1]["is_max"])
+        assert (got.score, got.offset, got.char_offset, got.ch) == (full.score, full.offset, full.char_offset, full.ch)
+
+
+def test_device_inputs_bad_alphabet_reported_at_wait(psa):
+    import torch
+    t1 = torch.frombuffer(bytearray(b"ABCDEFGHIJ" * 100 + b"abc"), dtype=torch.uint8).cuda()
+    t2 = torch.frombuffer(bytearray(b"ABCDEFG"), dtype=torch.uint8).cuda()
+    with psa.Context(0) as c:
+        c.set_weights([1, 1, 1, 1], True)
+        c.set_seq1_device(t1.data_ptr(), t1.numel())
+        c.set_seq2_device(t2.data_ptr(), t2.numel())
+        with pytest.raises(psa.PsaError) as e:
+            c.search()
+        assert e.value.status == psa.PSA_ERR_ALPHABET
+
+
+RESCORE_WEIGHTS = [
+    W_README, [0.8, 0.54, 2.6, 13.7], [1, 3, 4, 2], [2, 1.5, 1.1, 1.3],
+    [1e-3, 7.25, 7.25, 0.5], [123456.789, 0.001, 3.3e-7, 9.87], [0.1, 0.1, 0.1, 0.1],
+    [25.0, 1.0, 1.0, 1.0],            # near-zero drift: the running sum keeps crossing binades
+    [0, 0, 0, 0], [1.5, 0, 0.3, 0], [-1.25, 2.5, -0.75, 0.125], [1e300, 1e299, 3e298, 7e297],
+    [5e-324, 1.0, 2.0, 3.0],          # subnormal weight: integer walk disabled
+    [0.30000000000000004, 0.1 + 0.2, 1 / 3, 2 / 3],
+]
+
+
+@pytest.mark.parametrize("w", RESCORE_WEIGHTS)
+def test_rescore_walk_is_bit_exact(psa, oracle, w):
+    """The rescore kernel (integer walk inside a binade + plain fp64 chain elsewhere) against the
+    oracle's sequential sum for EVERY offset, random and structured sequences, both modes."""
+    rng = np.random.default_rng(11)
+    cases = [
+        (psa.generate_sequence(71, 6000), psa.generate_sequence(72, 4000)),     # long walk, 2001 offsets
+        (psa.generate_sequence(73, 2600), psa.generate_sequence(74, 601)),
+        (b"HERTHTGEKPYECHQC" * 180, b"HERTHTGEKPYECHQC" * 60 + b"HER"),        # periodic
+        (rng.choice(np.frombuffer(b"AL-", np.uint8), 3000).tobytes(), rng.choice(np.frombuffer(b"AL-", np.uint8), 1500).tobytes()),
+    ]
+    with psa.Context(0) as c:
+        for is_max in (True, False):
+            c.set_weights(w, is_max)
+            for s1, s2 in cases:
+                c.set_seq1(s1)
+                c.set_seq2(s2)
+                total = len(s1) - len(s2) + 1
+                offs = np.arange(total, dtype=np.int32)
+                got = np.concatenate([c.debug_rescore(offs[k:k + 2048]) for k in range(0, total, 2048)])
+                want, _, _ = oracle.scores(s1, s2, w, is_max)
+                assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (w, is_max, len(s2))

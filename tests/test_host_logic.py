@@ -16,7 +16,7 @@ SYMBOLS = [chr(ord("A") + k) for k in range(26)] + ["-"]
 
 def test_library_exports_every_declared_symbol(psa):
     header = open(os.path.join(ROOT, "include", "psa.h")).read()
-    declared = set(re.findall(r"^\s*(?:psa_status|double|void|const char\*)\s+(\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^\s*(?:psa_status|double|void|int|const char\*)\s+(\w+)\s*\(", header, re.M))
     assert declared == set(psa.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(psa.lib, name), name
