@@ -27,6 +27,12 @@ namespace psa {
 constexpr int kBlock = 256;
 
 
+struct SearchTail {   // everything the host reads back after a search, one D2H copy
+    psa_result result;
+    int        bad;       // alphabet flag of the encode kernels (bit 0 seq1, bit 1 seq2)
+    int        overflow;  // filter engine: the candidate list did not fit
+};
+
 struct BlockRec {     // per-block / per-shard arg-best
     double score;
     int    offset;    // INT_MAX = none
@@ -77,20 +83,6 @@ namespace psa {
 // ---------------------------------------------------------------------------
 // encode kernels: ASCII -> codes (psa_internal.hpp), flag anything else
 // ---------------------------------------------------------------------------
-__global__ void psa_encode_seq1(const unsigned char* __restrict__ raw, int n, unsigned char* __restrict__ codes,
-                                int capacity, int* __restrict__ bad)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= capacity) return;
-    int code = kCodePad;
-    if (i < n) {
-        const unsigned char c = raw[i];
-        code = (c >= 'A' && c <= 'Z') ? c - 'A' : (c == '-' ? kCodeHyphen : kCodeBad);
-        if (code == kCodeBad) { atomicOr(bad, 1); code = kCodePad; }
-    }
-    codes[i] = (unsigned char)code;
-}
-
 __global__ void psa_encode_seq2(const unsigned char* __restrict__ raw, int m, unsigned int* __restrict__ rows,
                                 unsigned char* __restrict__ bytes, int capacity, int* __restrict__ bad)
 {
@@ -204,7 +196,8 @@ struct FinalArgs {
     const unsigned int*  s2rows;
     const unsigned char* rank;
     const unsigned char* sub;
-    psa_result*          out;
+    SearchTail*          out;
+    const int*           bad;
     int m;
     int is_max;
     long long pairs;
@@ -232,12 +225,16 @@ __global__ __launch_bounds__(kBlock) void psa_finalize_kernel(FinalArgs a)
     const BlockRec w = s_win;
     if (w.offset == INT_MAX || w.rank == 0) {
         if (threadIdx.x == 0) {
-            a.out->score = is_max ? -INFINITY : INFINITY;
-            a.out->offset = -1;
-            a.out->char_offset = -1;
-            a.out->ch = 0;
-            a.out->shard = -1;
-            a.out->pairs = a.pairs;
+            psa_result r;
+            r.score = is_max ? -INFINITY : INFINITY;
+            r.offset = -1;
+            r.char_offset = -1;
+            r.ch = 0;
+            r.shard = -1;
+            r.pairs = a.pairs;
+            a.out->result = r;
+            a.out->bad = *a.bad;
+            a.out->overflow = 0;
         }
         return;
     }
@@ -251,12 +248,16 @@ __global__ __launch_bounds__(kBlock) void psa_finalize_kernel(FinalArgs a)
     if (threadIdx.x == 0) {
         const int i = s_first_i;
         const unsigned int idx = a.s2rows[i] * kRow + a.s1[w.offset + i];
-        a.out->score = w.score;
-        a.out->offset = w.offset;
-        a.out->char_offset = i;
-        a.out->ch = a.sub[idx];
-        a.out->shard = -1;
-        a.out->pairs = a.pairs;
+        psa_result r;
+        r.score = w.score;
+        r.offset = w.offset;
+        r.char_offset = i;
+        r.ch = a.sub[idx];
+        r.shard = -1;
+        r.pairs = a.pairs;
+        a.out->result = r;
+        a.out->bad = *a.bad;
+        a.out->overflow = 0;
     }
 }
 
@@ -304,7 +305,8 @@ constexpr int kSeq2Slack = 32768 + 64;
 
 struct Scalars {                      // small device-side state of one filter search
     int cand_count;
-    int overflow;
+    int done;                         // candidate workgroups that have finished re-scoring
+    int spare;
 };
 
 struct FilterPlan {
@@ -349,20 +351,19 @@ struct psa_context {
     unsigned*      d_letter_masks = nullptr;
     unsigned char* d_clsrank = nullptr;   // class | rank << 3 per pair (rescore kernel)
     psa::BlockRec* d_blocks = nullptr;  int blocks_cap = 0;
-    psa_result*    d_result = nullptr;
-    psa_result*    h_result = nullptr;   // pinned
+    psa::SearchTail* d_tail = nullptr;
+    psa::SearchTail* h_tail = nullptr;   // pinned
     int*           d_bad = nullptr;
     int*           h_bad = nullptr;      // pinned
 
     // filter engine
-    uint2*              d_masks = nullptr;   int nslots = 0;   bool masks_valid = false;
+    uint2*              d_masks = nullptr;   int nslots = 0;
     unsigned long long* d_partial = nullptr; size_t partial_cap = 0;
     double*             d_upper = nullptr;   size_t upper_cap = 0;
     Scalars*            d_scal = nullptr;
-    Scalars*            h_scal = nullptr;    // pinned
     int*                d_cand = nullptr;
-    psa::BlockRec*      d_rec = nullptr;
-    unsigned long long* d_block_best = nullptr;   // [kKeyBlocks]
+    psa::CandRec*       d_rec = nullptr;
+    unsigned long long* d_block_best = nullptr;   int block_best_cap = 0;
 
     psa_engine  engine = PSA_ENGINE_AUTO;
     int         forced_r = 0;
@@ -390,23 +391,12 @@ psa_status ensure_device(psa_context* c)
 psa_status upload_tables(psa_context* c)
 {
     const psa::Tables& t = c->tables;
-    // class planes of every Seq2 symbol b over the Seq1 symbols a:
-    // lo = class in {'*' (0), '.' (2)}, hi = class in {':' (1), '.' (2)}
-    unsigned letter[psa::kMaskRows * 2];
-    std::memset(letter, 0, sizeof letter);
-    for (int b = 0; b <= psa::kCodeHyphen; ++b)
-        for (int a = 0; a <= psa::kCodeHyphen; ++a) {
-            const int cls = t.cls[b * psa::kRow + a];
-            if (cls == 0 || cls == 2) letter[b * 2 + 0] |= 1u << a;
-            if (cls == 1 || cls == 2) letter[b * 2 + 1] |= 1u << a;
-        }
     PSA_HIP(hipMemcpyAsync(c->d_pair, t.pair, sizeof t.pair, hipMemcpyHostToDevice, c->stream));
     PSA_HIP(hipMemcpyAsync(c->d_rank, t.rank, sizeof t.rank, hipMemcpyHostToDevice, c->stream));
     PSA_HIP(hipMemcpyAsync(c->d_sub, t.sub, sizeof t.sub, hipMemcpyHostToDevice, c->stream));
     PSA_HIP(hipMemcpyAsync(c->d_delta, t.delta_of_rank, sizeof t.delta_of_rank, hipMemcpyHostToDevice, c->stream));
     unsigned char clsrank[psa::kRow * psa::kRow];
     for (int k = 0; k < psa::kRow * psa::kRow; ++k) clsrank[k] = (unsigned char)(t.cls[k] | (t.rank[k] << 3));
-    PSA_HIP(hipMemcpyAsync(c->d_letter_masks, letter, sizeof letter, hipMemcpyHostToDevice, c->stream));
     PSA_HIP(hipMemcpyAsync(c->d_clsrank, clsrank, sizeof clsrank, hipMemcpyHostToDevice, c->stream));
     PSA_HIP(hipStreamSynchronize(c->stream));   // host arrays go out of scope right after return
     return PSA_OK;
@@ -433,6 +423,8 @@ psa_status report_bad(psa_context* c)
     return PSA_ERR_ALPHABET;
 }
 
+// Seq1: symbol codes + the filter engine's class planes, one fused kernel
+// (the planes do not depend on the weights, only on the group tables).
 psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
 {
     const int need = (n + kSeq1Slack + 63) & ~63;
@@ -445,9 +437,15 @@ psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
         if (st != PSA_OK) return st;
     }
     c->n = -1;
-    c->masks_valid = false;
-    hipLaunchKernelGGL(psa::psa_encode_seq1, dim3((c->n_cap + 255) / 256), dim3(256), 0, c->stream,
-                       static_cast<const unsigned char*>(d_raw), n, c->d_s1, c->n_cap, c->d_bad);
+    psa::PrepareArgs a;
+    a.raw = static_cast<const unsigned char*>(d_raw);
+    a.codes = c->d_s1;
+    a.masks = c->d_masks;
+    a.symbol_planes = c->d_letter_masks;
+    a.bad = c->d_bad;
+    a.n = n;
+    a.nslots = c->nslots;
+    hipLaunchKernelGGL(psa::psa_prepare_seq1_kernel, dim3((c->nslots + 255) / 256), dim3(256), 0, c->stream, a);
     PSA_HIP(hipGetLastError());
     c->n = n;
     return PSA_OK;
@@ -544,7 +542,8 @@ psa_status launch_sequential(psa_context* c, int first, int last, double* per_sc
     f.s2rows = c->d_s2rows;
     f.rank = c->d_rank;
     f.sub = c->d_sub;
-    f.out = c->d_result;
+    f.out = c->d_tail;
+    f.bad = c->d_bad;
     f.m = c->m;
     f.is_max = c->tables.is_max;
     f.pairs = (long long)span * (long long)c->m;
@@ -608,20 +607,6 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
     return found;
 }
 
-psa_status ensure_masks(psa_context* c)
-{
-    if (c->masks_valid) return PSA_OK;
-    psa::MaskArgs a;
-    a.s1 = c->d_s1;
-    a.masks = c->d_masks;
-    a.letter_masks = c->d_letter_masks;
-    a.nslots = c->nslots;
-    hipLaunchKernelGGL(psa::psa_build_masks_kernel, dim3((c->nslots + 255) / 256), dim3(256), 0, c->stream, a);
-    PSA_HIP(hipGetLastError());
-    c->masks_valid = true;
-    return PSA_OK;
-}
-
 double filter_slack(const psa_context* c)
 {
     // |sequential fp64 sum - exact sum| <= (m-1) u sum|p_i| / (1 - (m-1) u)   (u = 2^-53),
@@ -635,7 +620,26 @@ double filter_slack(const psa_context* c)
     return 2.0 * 1.05 * ((double)c->m + 32.0) * u * mag;
 }
 
-psa_status launch_count(psa_context* c, const FilterPlan& p, int base, int span_pad)
+double filter_slack(const psa_context* c);
+
+psa::BoundParams bound_params(const psa_context* c)
+{
+    const psa::Tables& t = c->tables;
+    psa::BoundParams b;
+    for (int i = 0; i < 4; ++i) {
+        b.w[i] = t.weights[i];
+        b.class_best[i] = t.class_best_delta[i];
+        b.class_worst[i] = t.class_worst_delta[i];
+    }
+    b.slack = filter_slack(c);
+    b.m = c->m;
+    b.is_max = t.is_max;
+    return b;
+}
+
+// first/span describe the searched range when the kernel should also produce the score
+// bounds (single-chunk plans); span = 0 writes raw partial counts instead.
+psa_status launch_count(psa_context* c, const FilterPlan& p, int base, int span_pad, int first, int span)
 {
     psa::CountArgs a;
     a.masks = c->d_masks;
@@ -647,6 +651,12 @@ psa_status launch_count(psa_context* c, const FilterPlan& p, int base, int span_
     a.chunk_chars = p.chunk_chars;
     a.wave_chars = p.wave_chars;
     a.lds_slots = p.lds_slots;
+    a.zero = &c->d_scal->cand_count;      // the search scalars: cleared here for the kernels behind this one
+    a.upper = span > 0 ? c->d_upper : nullptr;
+    a.block_best = c->d_block_best;
+    a.lead = first - base;
+    a.span = span;
+    a.bounds = bound_params(c);
     const dim3 grid(p.ntiles, p.nchunks);
     if (p.waves == 16) {
         PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16>),
@@ -663,17 +673,22 @@ psa_status launch_count(psa_context* c, const FilterPlan& p, int base, int span_
     return PSA_OK;
 }
 
-psa_status launch_rescore(psa_context* c)
+psa_status launch_rescore(psa_context* c, long long pairs)
 {
     const psa::Tables& t = c->tables;
     psa::RescoreArgs r;
     r.s1 = c->d_s1;
     r.s2 = c->d_s2bytes;
     r.clsrank = c->d_clsrank;
+    r.sub = c->d_sub;
     r.delta_of_rank = c->d_delta;
     r.cand = c->d_cand;
     r.cand_count = &c->d_scal->cand_count;
     r.rec = c->d_rec;
+    r.done = &c->d_scal->done;
+    r.out = c->d_tail;
+    r.bad = c->d_bad;
+    r.pairs = pairs;
     r.class_value[0] = t.weights[0];       // get_weight, cuda_funcs.cu:442-452
     r.class_value[1] = -t.weights[1];
     r.class_value[2] = -t.weights[2];
@@ -697,7 +712,7 @@ psa_status launch_rescore(psa_context* c)
         r.fast_ok = ok && std::getenv("PSA_RESCORE_CHAIN") == nullptr;
         r.fast_min_exp = max_exp + 2;
     }
-    hipLaunchKernelGGL(psa::psa_rescore_kernel, dim3(kCandCap), dim3(64), 0, c->stream, r);
+    hipLaunchKernelGGL(psa::psa_rescore_kernel, dim3(kCandCap), dim3(psa::kRescoreThreads), 0, c->stream, r);
     PSA_HIP(hipGetLastError());
 
     return PSA_OK;
@@ -713,78 +728,63 @@ psa_status launch_filter(psa_context* c, int first, int last)
         return PSA_ERR_ARG;
     }
     const int span_pad = p.ntiles * psa::kTile;
-    const size_t need_partial = (size_t)p.nchunks * span_pad;
-    if (need_partial > c->partial_cap) {
-        psa_status st = dev_alloc(&c->d_partial, need_partial);
-        if (st != PSA_OK) { c->partial_cap = 0; return st; }
-        c->partial_cap = need_partial;
+    const bool inline_keys = p.nchunks == 1;
+    if (!inline_keys) {
+        const size_t need_partial = (size_t)p.nchunks * span_pad;
+        if (need_partial > c->partial_cap) {
+            psa_status st = dev_alloc(&c->d_partial, need_partial);
+            if (st != PSA_OK) { c->partial_cap = 0; return st; }
+            c->partial_cap = need_partial;
+        }
     }
     if ((size_t)span > c->upper_cap) {
         psa_status st = dev_alloc(&c->d_upper, (size_t)span);
         if (st != PSA_OK) { c->upper_cap = 0; return st; }
         c->upper_cap = (size_t)span;
     }
-    PSA_HIP(hipMemsetAsync(c->d_scal, 0, sizeof(Scalars), c->stream));
-    psa_status st = ensure_masks(c);
-    if (st != PSA_OK) return st;
+    if (p.ntiles > c->block_best_cap) {
+        psa_status st = dev_alloc(&c->d_block_best, (size_t)p.ntiles);
+        if (st != PSA_OK) { c->block_best_cap = 0; return st; }
+        c->block_best_cap = p.ntiles;
+    }
 
     if (c->profiling) PSA_HIP(hipEventRecord(c->ev[2], c->stream));
-    st = launch_count(c, p, base, span_pad);
+    psa_status st = launch_count(c, p, base, span_pad, first, inline_keys ? span : 0);
     if (st != PSA_OK) return st;
     if (c->profiling) PSA_HIP(hipEventRecord(c->ev[3], c->stream));
 
-    const psa::Tables& t = c->tables;
-    psa::KeyArgs k;
-    k.partial = c->d_partial;
-    k.upper = c->d_upper;
-    k.block_best = c->d_block_best;
-    for (int i = 0; i < 4; ++i) {
-        k.w[i] = t.weights[i];
-        k.class_best[i] = t.class_best_delta[i];
-        k.class_worst[i] = t.class_worst_delta[i];
+    int nbest = p.ntiles;
+    if (!inline_keys) {
+        psa::KeyArgs k;
+        k.partial = c->d_partial;
+        k.upper = c->d_upper;
+        k.block_best = c->d_block_best;
+        k.bounds = bound_params(c);
+        k.nchunks = p.nchunks;
+        k.span_pad = span_pad;
+        k.span = span;
+        k.lead = first - base;
+        nbest = std::min(psa::kKeyBlocks, (span + 255) / 256);
+        hipLaunchKernelGGL(psa::psa_keys_kernel, dim3(nbest), dim3(256), 0, c->stream, k);
+        PSA_HIP(hipGetLastError());
     }
-    k.slack = filter_slack(c);
-    k.nchunks = p.nchunks;
-    k.span_pad = span_pad;
-    k.span = span;
-    k.lead = first - base;
-    k.m = c->m;
-    k.is_max = t.is_max;
-    const int key_blocks = std::min(psa::kKeyBlocks, (span + 255) / 256);
-    hipLaunchKernelGGL(psa::psa_keys_kernel, dim3(key_blocks), dim3(256), 0, c->stream, k);
-    PSA_HIP(hipGetLastError());
 
     psa::SelectArgs s;
     s.upper = c->d_upper;
     s.block_best = c->d_block_best;
-    s.nbest = key_blocks;
+    s.nbest = nbest;
     s.cand = c->d_cand;
     s.cand_count = &c->d_scal->cand_count;
     s.span = span;
     s.first = first;
     s.cap = kCandCap;
-    hipLaunchKernelGGL(psa::psa_select_kernel, dim3(key_blocks), dim3(256), 0, c->stream, s);
+    hipLaunchKernelGGL(psa::psa_select_kernel, dim3(std::min(psa::kKeyBlocks, (span + 255) / 256)), dim3(256), 0,
+                       c->stream, s);
     PSA_HIP(hipGetLastError());
 
-    psa_status rst = launch_rescore(c);
+    psa_status rst = launch_rescore(c, (long long)span * (long long)c->m);
     if (rst != PSA_OK) return rst;
 
-    psa::FoldArgs f;
-    f.rec = c->d_rec;
-    f.cand_count = &c->d_scal->cand_count;
-    f.s1 = c->d_s1;
-    f.s2 = c->d_s2bytes;
-    f.rank = c->d_rank;
-    f.sub = c->d_sub;
-    f.out = c->d_result;
-    f.overflow = &c->d_scal->overflow;
-    f.m = c->m;
-    f.cap = kCandCap;
-    f.is_max = t.is_max;
-    f.pairs = (long long)span * (long long)c->m;
-    hipLaunchKernelGGL(psa::psa_fold_kernel, dim3(1), dim3(256), 0, c->stream, f);
-    PSA_HIP(hipGetLastError());
-    PSA_HIP(hipMemcpyAsync(c->h_scal, c->d_scal, sizeof(Scalars), hipMemcpyDeviceToHost, c->stream));
     return PSA_OK;
 }
 
@@ -843,19 +843,33 @@ psa_status psa_create(int device, void* stream, psa_context** out)
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_rank), psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_sub), psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_delta), sizeof(double) * psa::kMaxRanks));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_letter_masks), sizeof(unsigned) * psa::kMaskRows * 2));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_result), sizeof(psa_result)));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_letter_masks), sizeof(unsigned) * 64));
+        {
+            // class planes of every Seq1 symbol a over the Seq2 symbols b (group tables only):
+            // word a: bit b = class(a, b) in {'*', '.'};  word 32+a: class in {':', '.'}
+            unsigned planes[64];
+            std::memset(planes, 0, sizeof planes);
+            for (int a = 0; a <= psa::kCodeHyphen; ++a)
+                for (int b = 0; b <= psa::kCodeHyphen; ++b) {
+                    const char sign = psa::sign_of(a, b);
+                    if (sign == PSA_SIGN_STAR || sign == PSA_SIGN_DOT) planes[a] |= 1u << b;
+                    if (sign == PSA_SIGN_COLON || sign == PSA_SIGN_DOT) planes[32 + a] |= 1u << b;
+                }
+            PSA_HIP(hipMemcpyAsync(c->d_letter_masks, planes, sizeof planes, hipMemcpyHostToDevice, c->stream));
+            PSA_HIP(hipStreamSynchronize(c->stream));
+        }
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_tail), sizeof(psa::SearchTail)));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bad), sizeof(int)));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scal), sizeof(Scalars)));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_cand), sizeof(int) * kCandCap));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_rec), sizeof(psa::BlockRec) * kCandCap));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_rec), sizeof(psa::CandRec) * kCandCap));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_clsrank), psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_block_best), sizeof(unsigned long long) * psa::kKeyBlocks));
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_result), sizeof(psa_result), hipHostMallocDefault));
+        c->block_best_cap = psa::kKeyBlocks;
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_tail), sizeof(psa::SearchTail), hipHostMallocDefault));
         PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_bad), sizeof(int), hipHostMallocDefault));
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_scal), sizeof(Scalars), hipHostMallocDefault));
         *c->h_bad = 0;
-        std::memset(c->h_scal, 0, sizeof(Scalars));
+        std::memset(c->h_tail, 0, sizeof(psa::SearchTail));
         PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
         for (auto& ev : c->ev) PSA_HIP(hipEventCreate(&ev));
         PSA_HIP(hipStreamSynchronize(c->stream));
@@ -883,7 +897,7 @@ void psa_destroy(psa_context* c)
     (void)hipFree(c->d_letter_masks);
     (void)hipFree(c->d_clsrank);
     (void)hipFree(c->d_blocks);
-    (void)hipFree(c->d_result);
+    (void)hipFree(c->d_tail);
     (void)hipFree(c->d_bad);
     (void)hipFree(c->d_masks);
     (void)hipFree(c->d_partial);
@@ -892,9 +906,8 @@ void psa_destroy(psa_context* c)
     (void)hipFree(c->d_cand);
     (void)hipFree(c->d_rec);
     (void)hipFree(c->d_block_best);
-    if (c->h_result) (void)hipHostFree(c->h_result);
+    if (c->h_tail) (void)hipHostFree(c->h_tail);
     if (c->h_bad) (void)hipHostFree(c->h_bad);
-    if (c->h_scal) (void)hipHostFree(c->h_scal);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -980,8 +993,7 @@ psa_status psa_search_async(psa_context* c, int first, int last)
     c->pending_last = last;
     st = c->pending_filter ? launch_filter(c, first, last) : launch_sequential(c, first, last, nullptr, nullptr);
     if (st != PSA_OK) return st;
-    PSA_HIP(hipMemcpyAsync(c->h_result, c->d_result, sizeof(psa_result), hipMemcpyDeviceToHost, c->stream));
-    PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PSA_HIP(hipMemcpyAsync(c->h_tail, c->d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
     if (c->profiling) {
         PSA_HIP(hipEventRecord(c->ev[1], c->stream));
         c->timing_valid = true;
@@ -996,19 +1008,20 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
     if (!c->pending) { set_last_error("psa_search_wait: no search in flight"); return PSA_ERR_STATE; }
     PSA_HIP(hipStreamSynchronize(c->stream));
     c->pending = false;
+    *c->h_bad = c->h_tail->bad;
     psa_status st = report_bad(c);            // device-resident sequences are validated here
     if (st != PSA_OK) return st;
-    if (c->pending_filter && c->h_scal->overflow) {
+    if (c->pending_filter && c->h_tail->overflow) {
         // more near-tied offsets than the candidate list holds (e.g. a homopolymer):
         // score every offset in reference order instead
         c->fallbacks += 1;
         st = launch_sequential(c, c->pending_first, c->pending_last, nullptr, nullptr);
         if (st != PSA_OK) return st;
-        PSA_HIP(hipMemcpyAsync(c->h_result, c->d_result, sizeof(psa_result), hipMemcpyDeviceToHost, c->stream));
+        PSA_HIP(hipMemcpyAsync(c->h_tail, c->d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
         PSA_HIP(hipStreamSynchronize(c->stream));
         c->timing_valid = false;
     }
-    *out = *c->h_result;
+    *out = c->h_tail->result;
     if (c->profiling && c->timing_valid) {
         float a = 0.f, b = 0.f;
         PSA_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
@@ -1083,9 +1096,7 @@ psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_sta
         if (st != PSA_OK) { c->partial_cap = 0; return st; }
         c->partial_cap = need;
     }
-    st = ensure_masks(c);
-    if (st != PSA_OK) return st;
-    st = launch_count(c, p, base, span_pad);
+    st = launch_count(c, p, base, span_pad, first, 0);
     if (st != PSA_OK) return st;
     std::vector<unsigned long long> host(need);
     PSA_HIP(hipMemcpyAsync(host.data(), c->d_partial, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1122,13 +1133,14 @@ psa_status psa_debug_rescore(psa_context* c, const int32_t* offsets, int count, 
         if (offsets[k] < 0 || offsets[k] >= total) { set_last_error("psa_debug_rescore: offset out of range"); return PSA_ERR_ARG; }
     Scalars sc;
     sc.cand_count = count;
-    sc.overflow = 0;
+    sc.done = 0;
+    sc.spare = 0;
     PSA_HIP(hipMemcpyAsync(c->d_scal, &sc, sizeof sc, hipMemcpyHostToDevice, c->stream));
     PSA_HIP(hipMemcpyAsync(c->d_cand, offsets, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    st = launch_rescore(c);
+    st = launch_rescore(c, 0);
     if (st != PSA_OK) return st;
-    std::vector<psa::BlockRec> host((size_t)count);
-    PSA_HIP(hipMemcpyAsync(host.data(), c->d_rec, sizeof(psa::BlockRec) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    std::vector<psa::CandRec> host((size_t)count);
+    PSA_HIP(hipMemcpyAsync(host.data(), c->d_rec, sizeof(psa::CandRec) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     PSA_HIP(hipStreamSynchronize(c->stream));
     st = report_bad(c);

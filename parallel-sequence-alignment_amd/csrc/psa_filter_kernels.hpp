@@ -98,37 +98,81 @@ struct SlicedCounter {
 };
 
 // ---- Seq1 class planes --------------------------------------------------------
-// letter_masks[b*2 + 0] = 27-bit set of Seq1 symbols a with class(a, b) in {'*', '.'}
-// letter_masks[b*2 + 1] = ... with class(a, b) in {':', '.'}
-struct MaskArgs {
-    const unsigned char* s1;          // codes, padded with kCodePad to 32*nslots
-    uint2*               masks;       // [kMaskRows][nslots]: {lo, hi} of 32 Seq1 positions
-    const unsigned*      letter_masks;  // [kMaskRows*2]
+// For every Seq2 symbol b (row) and every 32 Seq1 positions (slot) the kernel
+// stores {lo, hi}: bit t of lo = class(Seq1[32*slot+t], b) in {'*','.'}, of hi =
+// class in {':','.'}.  symbol_planes[a] / [32+a] hold the same relation as a
+// column: bit b = lo / hi of (a, b); a thread fetches the 32 columns of its slot
+// and transposes the 32x32 bit matrix in registers.
+struct PrepareArgs {
+    const unsigned char* raw;         // Seq1 as ASCII (device), n bytes
+    unsigned char*       codes;       // [32*nslots]: symbol codes, kCodePad behind n
+    uint2*               masks;       // [kMaskRows][nslots]
+    const unsigned*      symbol_planes;  // [64]
+    int*                 bad;
+    int                  n;
     int                  nslots;
 };
 
-__global__ __launch_bounds__(256) void psa_build_masks_kernel(MaskArgs a)
+__device__ __forceinline__ void transpose32(unsigned (&a)[32])
 {
-    __shared__ unsigned s_letter[kMaskRows * 2];
-    if (threadIdx.x < kMaskRows * 2) s_letter[threadIdx.x] = a.letter_masks[threadIdx.x];
+    // out[b] bit t = in[t] bit b  (recursive block swap, Hacker's Delight 7-3, mirrored)
+    unsigned m = 0x0000ffffu;
+#pragma unroll
+    for (int j = 16; j != 0; j >>= 1, m ^= (m << j)) {
+#pragma unroll
+        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+            const unsigned t = ((a[k] >> j) ^ a[k + j]) & m;
+            a[k] ^= t << j;
+            a[k + j] ^= t;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void psa_prepare_seq1_kernel(PrepareArgs a)
+{
+    __shared__ unsigned s_planes[64];
+    if (threadIdx.x < 64) s_planes[threadIdx.x] = a.symbol_planes[threadIdx.x];
     __syncthreads();
     const int slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= a.nslots) return;
-    const uint4* src = reinterpret_cast<const uint4*>(a.s1 + (size_t)slot * 32);
-    const uint4 c0 = src[0], c1 = src[1];
-    const unsigned w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-    // one-hot of each position's symbol, then every symbol row is a 32-way bit gather
-    for (int b = 0; b < kMaskRows; ++b) {
-        const unsigned klo = s_letter[b * 2 + 0], khi = s_letter[b * 2 + 1];
-        unsigned lo = 0u, hi = 0u;
+    const int p0 = slot * 32;
+    unsigned w[8];
+    if (p0 + 32 <= a.n && (reinterpret_cast<size_t>(a.raw) & 15) == 0) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.raw + p0);
+        const uint4 c0 = src[0], c1 = src[1];
+        w[0] = c0.x; w[1] = c0.y; w[2] = c0.z; w[3] = c0.w; w[4] = c1.x; w[5] = c1.y; w[6] = c1.z; w[7] = c1.w;
+    } else {
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            const unsigned code = (w[t >> 2] >> (8 * (t & 3))) & 0xffu;   // 0..27
-            lo |= ((klo >> code) & 1u) << t;
-            hi |= ((khi >> code) & 1u) << t;
+        for (int q = 0; q < 8; ++q) {
+            unsigned v = 0u;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = p0 + 4 * q + r;
+                v |= (p < a.n ? (unsigned)a.raw[p] : (unsigned)'\xff') << (8 * r);
+            }
+            w[q] = v;
         }
-        a.masks[(size_t)b * a.nslots + slot] = make_uint2(lo, hi);
     }
+    unsigned lo[32], hi[32], cw[8];
+    bool any_bad = false;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const unsigned c = (w[t >> 2] >> (8 * (t & 3))) & 0xffu;
+        unsigned code = c - 'A' < 26u ? c - 'A' : (c == '-' ? (unsigned)kCodeHyphen : (unsigned)kCodePad);
+        if (code == (unsigned)kCodePad && p0 + t < a.n) any_bad = true;      // a real character outside [A-Z-]
+        if ((t & 3) == 0) cw[t >> 2] = 0u;
+        cw[t >> 2] |= code << (8 * (t & 3));
+        lo[t] = s_planes[code];
+        hi[t] = s_planes[32 + code];
+    }
+    if (any_bad) atomicOr(a.bad, 1);
+    uint4* dst = reinterpret_cast<uint4*>(a.codes + p0);
+    dst[0] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+    dst[1] = make_uint4(cw[4], cw[5], cw[6], cw[7]);
+    transpose32(lo);
+    transpose32(hi);
+#pragma unroll
+    for (int b = 0; b < kMaskRows; ++b) a.masks[(size_t)b * a.nslots + slot] = make_uint2(lo[b], hi[b]);
 }
 
 // One char of the count loop: J is its index inside the round.  Tiles start on
@@ -170,6 +214,50 @@ __device__ __forceinline__ void count_round(SlicedCounter (&cnt)[2][kCounters],
     (count_step<Js>(cnt, packed, lds_lane, row_bytes), ...);
 }
 
+// ---- score interval of one offset from its exact counts ------------------------
+struct BoundParams {
+    double w[4];
+    double class_best[4];    // most favourable substitution delta inside each class
+    double class_worst[4];   // least favourable delta inside each class
+    double slack;            // rounding bound of the sequential sum + this formula
+    int m;
+    int is_max;
+};
+
+// monotone map double -> u64 (total order, -0 < +0)
+__device__ __forceinline__ unsigned long long order_key(double x)
+{
+    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_order(unsigned long long k)
+{
+    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+    return __longlong_as_double((long long)u);
+}
+
+// optimistic ("upper") and pessimistic score of an offset in "bigger is better" form
+// (MIN searches are negated), each widened by the rounding slack
+__device__ __forceinline__ void offset_bounds(const BoundParams& b, int n_lo, int n_hi, int n_both,
+                                              double& upper, double& pess)
+{
+    const bool mx = b.is_max != 0;
+    const int n0 = n_lo - n_both, n1 = n_hi - n_both, n2 = n_both;   // stars, colons, dots
+    const int n3 = b.m - n0 - n1 - n2;
+    const double total = ((b.w[0] * n0 - b.w[1] * n1) - b.w[2] * n2) - b.w[3] * n3;
+    const int n[4] = {n0, n1, n2, n3};
+    double d_opt = mx ? -INFINITY : INFINITY, d_pes = mx ? -INFINITY : INFINITY;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (n[k] > 0) {
+            d_opt = mx ? fmax(d_opt, b.class_best[k]) : fmin(d_opt, b.class_best[k]);
+            d_pes = mx ? fmax(d_pes, b.class_worst[k]) : fmin(d_pes, b.class_worst[k]);
+        }
+    const double sgn = mx ? 1.0 : -1.0;
+    upper = sgn * (total + d_opt) + b.slack;
+    pess = sgn * (total + d_pes) - b.slack;
+}
+
 // ---- count kernel --------------------------------------------------------------
 struct CountArgs {
     const uint2*         masks;     // [kMaskRows][nslots]
@@ -181,6 +269,13 @@ struct CountArgs {
     int chunk_chars;  // chars per chunk (multiple of kUnroll * waves)
     int wave_chars;   // chars per wave   (multiple of kUnroll, <= kMaxWaveChars)
     int lds_slots;    // slots per staged row
+    int* zero;        // three ints cleared for the kernels behind this one (candidate count, arrivals, spare)
+    // single-chunk searches finish the counts here: bounds per offset + best pessimistic bound per tile
+    double*             upper;        // [span] or NULL (then `partial` is written and psa_keys_kernel runs)
+    unsigned long long* block_best;   // [gridDim.x]
+    int lead;                         // offsets of tile 0 in front of the range (first - base)
+    int span;
+    BoundParams bounds;
 };
 
 template <int WAVES>
@@ -193,6 +288,7 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     const int tile_o0 = a.base + blockIdx.x * kTile;           // absolute offset of word 0, bit 0 (multiple of 32)
     const int chunk_c0 = blockIdx.y * a.chunk_chars;           // first char of this chunk (multiple of 32)
     const int slot0 = (tile_o0 + chunk_c0) >> 5;               // first staged slot
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && a.zero) { a.zero[0] = 0; a.zero[1] = 0; a.zero[2] = 0; }
 
     // stage the 28 plane rows of the window [tile_o0+chunk_c0, +kTile+chunk_chars): rows dealt to waves
     for (int b = wave; b < kMaskRows; b += WAVES) {
@@ -295,83 +391,78 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     const int o_local = tid * kPer;
     const int word = o_local >> 5;
     const int bit0 = o_local & 31;
-    unsigned long long out[kPer];
-#pragma unroll
-    for (int e = 0; e < kPer; ++e) out[e] = 0ull;
+    unsigned n[kCounters][kPer];
 #pragma unroll
     for (int k = 0; k < kCounters; ++k) {
-        unsigned n[kPer];
 #pragma unroll
-        for (int e = 0; e < kPer; ++e) n[e] = 0u;
+        for (int e = 0; e < kPer; ++e) n[k][e] = 0u;
 #pragma unroll
         for (int p = 0; p < kMergedPlanes; ++p) {
             const unsigned v = pub[(k * kMergedPlanes + p) * 128 + word] >> bit0;
 #pragma unroll
-            for (int e = 0; e < kPer; ++e) n[e] |= ((v >> e) & 1u) << p;
+            for (int e = 0; e < kPer; ++e) n[k][e] |= ((v >> e) & 1u) << p;
         }
-#pragma unroll
-        for (int e = 0; e < kPer; ++e) out[e] |= (unsigned long long)n[e] << (21 * k);
     }
-    unsigned long long* dst = a.partial + (size_t)blockIdx.y * a.span_pad + (size_t)blockIdx.x * kTile + o_local;
+    if (a.upper == nullptr) {
+        unsigned long long* dst = a.partial + (size_t)blockIdx.y * a.span_pad + (size_t)blockIdx.x * kTile + o_local;
 #pragma unroll
-    for (int e = 0; e < kPer; ++e) dst[e] = out[e];
+        for (int e = 0; e < kPer; ++e)
+            dst[e] = (unsigned long long)n[0][e] | ((unsigned long long)n[1][e] << 21) | ((unsigned long long)n[2][e] << 42);
+        return;
+    }
+    // one chunk: the counts are final
+    double pess = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < kPer; ++e) {
+        const int o = (int)blockIdx.x * kTile + o_local + e - a.lead;      // relative to the range's first offset
+        if (o >= 0 && o < a.span) {
+            double up, pe;
+            offset_bounds(a.bounds, (int)n[0][e], (int)n[1][e], (int)n[2][e], up, pe);
+            a.upper[o] = up;
+            pess = fmax(pess, pe);
+        }
+    }
+    unsigned long long key = order_key(pess);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long other = __shfl_xor(key, d, 64);
+        key = other > key ? other : key;
+    }
+    __syncthreads();                                  // everyone is done reading `pub`
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(scratch);
+    if (lane == 0) s_best[wave] = key;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < WAVES; ++w) key = s_best[w] > key ? s_best[w] : key;
+        a.block_best[blockIdx.x] = key;
+    }
 }
 
-// ---- keys: counts -> score interval per offset; global best bound --------------
+// ---- keys (searches with several char chunks): counts -> score interval per offset
 struct KeyArgs {
     const unsigned long long* partial;   // [nchunks][span_pad]
     double*                   upper;     // [span]: optimistic score of every offset
     unsigned long long*       block_best;  // [gridDim.x]: ordered-u64 of each block's best pessimistic score
-    double w[4];
-    double class_best[4];    // most favourable delta inside each class
-    double class_worst[4];   // least favourable delta inside each class
-    double slack;            // rounding bound of the sequential sum + this formula
+    BoundParams bounds;
     int nchunks;
     int span_pad;
     int span;
     int lead;         // offsets of tile 0 in front of the range (first - base)
-    int m;
-    int is_max;
 };
-
-// monotone map double -> u64 (total order, -0 < +0)
-__device__ __forceinline__ unsigned long long order_key(double x)
-{
-    const unsigned long long u = (unsigned long long)__double_as_longlong(x);
-    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double key_order(unsigned long long k)
-{
-    const unsigned long long u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
-    return __longlong_as_double((long long)u);
-}
 
 constexpr int kKeyBlocks = 1024;   // grid of the keys / select kernels (grid-stride over the offsets)
 
 __global__ __launch_bounds__(256) void psa_keys_kernel(KeyArgs a)
 {
     __shared__ unsigned long long s_best[4];
-    const bool mx = a.is_max != 0;
-    // in MIN mode everything is negated so that "best" is always the maximum
-    const double sgn = mx ? 1.0 : -1.0;
     double pess = -INFINITY;
     for (int o = blockIdx.x * 256 + threadIdx.x; o < a.span; o += gridDim.x * 256) {
         unsigned long long sum = 0ull;
         for (int c = 0; c < a.nchunks; ++c) sum += a.partial[(size_t)c * a.span_pad + a.lead + o];
-        const int n_lo = (int)(sum & 0x1fffff), n_hi = (int)((sum >> 21) & 0x1fffff), n2 = (int)((sum >> 42) & 0x1fffff);
-        const int n0 = n_lo - n2, n1 = n_hi - n2;          // stars, colons; n2 = dots
-        const int n3 = a.m - n0 - n1 - n2;
-        const double total = ((a.w[0] * n0 - a.w[1] * n1) - a.w[2] * n2) - a.w[3] * n3;
-        const int n[4] = {n0, n1, n2, n3};
-        double d_opt = mx ? -INFINITY : INFINITY, d_pes = mx ? -INFINITY : INFINITY;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (n[k] > 0) {
-                d_opt = mx ? fmax(d_opt, a.class_best[k]) : fmin(d_opt, a.class_best[k]);
-                d_pes = mx ? fmax(d_pes, a.class_worst[k]) : fmin(d_pes, a.class_worst[k]);
-            }
-        a.upper[o] = sgn * (total + d_opt) + a.slack;            // optimistic, in "bigger is better" form
-        pess = fmax(pess, sgn * (total + d_pes) - a.slack);      // pessimistic
+        double up, pe;
+        offset_bounds(a.bounds, (int)(sum & 0x1fffff), (int)((sum >> 21) & 0x1fffff), (int)((sum >> 42) & 0x1fffff), up, pe);
+        a.upper[o] = up;
+        pess = fmax(pess, pe);
     }
     unsigned long long key = order_key(pess);
 #pragma unroll
@@ -436,14 +527,27 @@ __global__ __launch_bounds__(256) void psa_select_kernel(SelectArgs a)
 // binade, binades where an addend falls exactly between two grid points (a
 // round-half-even tie) and the first chars (|sum| comparable to the addends) run
 // the plain chain of v_add_f64.
+struct CandRec {                    // one re-scored candidate
+    double score;                   // exact total + best delta
+    int    offset;
+    int    char_offset;             // first char with the best delta rank
+    int    rank;                    // 0 = no substitution possible
+    int    ch;                      // substituted character
+};
+
 struct RescoreArgs {
     const unsigned char* s1;
     const unsigned char* s2;        // byte codes
     const unsigned char* clsrank;   // [32][32]: class (bits 0-2) | delta rank (bits 3-7), [c2][c1]
+    const unsigned char* sub;       // [32][32]
     const double*        delta_of_rank;
     const int*           cand;
     const int*           cand_count;
-    BlockRec*            rec;       // [cap]: exact score, offset, best rank
+    CandRec*             rec;       // [cap]
+    int*                 done;      // arrival counter of the candidate workgroups (cleared by the count kernel)
+    SearchTail*          out;       // written by the last workgroup to arrive
+    const int*           bad;       // the encode kernels' alphabet flag
+    long long            pairs;
     double class_value[8];          // pair score of class 0..3, +0.0 for the padding class 4
     int m;
     int cap;
@@ -452,227 +556,269 @@ struct RescoreArgs {
     int fast_min_exp;               // smallest biased exponent of the running sum the walk handles
 };
 
-constexpr int kRescoreEpl = 8;      // chars per lane and batch on the integer walk
+constexpr int kRescoreEpl = 8;          // chars per lane and batch on the integer walk
+constexpr int kRescoreThreads = 512;
+constexpr int kRescoreChunk = 32768;    // chars whose class codes are staged in LDS at a time
 
-__device__ __forceinline__ long long wave_scan_inclusive(long long v, int lane)
+// Inclusive prefix sum of a 64-bit value over the 64 lanes, by DPP row shifts and row
+// broadcasts (register-to-register; no LDS round trips as __shfl_up would need).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_add(long long v)
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const long long t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return v + (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ long long wave_scan_inclusive(long long v)
+{
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> inclusive scan inside each row of 16 lanes
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
     return v;
 }
 
-__global__ __launch_bounds__(64) void psa_rescore_kernel(RescoreArgs a)
+__device__ __forceinline__ long long readlane64(long long v, int l)
 {
-    __shared__ unsigned char s_clsrank[kRow * kRow];
-    __shared__ double        s_vals[64];
-    __shared__ long long     s_round[8];
+    const unsigned lo = __builtin_amdgcn_readlane((int)v, l);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// One workgroup per candidate.  All four waves classify the chars of a chunk into LDS
+// (class | rank codes; loads of the whole chunk in flight together) and track the best
+// delta rank and its first position; wave 0 then runs the summation over the staged codes.
+__global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArgs a)
+{
+    __shared__ unsigned char      s_clsrank[kRow * kRow];
+    __shared__ __attribute__((aligned(16))) unsigned char s_codes[kRescoreChunk + 64 * kRescoreEpl + 16];
+    __shared__ double             s_vals[64];
+    __shared__ long long          s_round[8];
+    __shared__ unsigned long long s_key[kRescoreThreads / 64];
     int count = *a.cand_count;
     if (count > a.cap) count = a.cap;
     if ((int)blockIdx.x >= count) return;
-    const int lane = threadIdx.x;
-    for (int k = lane; k < kRow * kRow; k += 64) s_clsrank[k] = a.clsrank[k];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    for (int k = tid; k < kRow * kRow; k += kRescoreThreads) s_clsrank[k] = a.clsrank[k];
     __syncthreads();
     const int o = a.cand[blockIdx.x];
     const unsigned char* s1 = a.s1 + o;
     const int m = a.m;
 
-    double s = 0.0;             // running sum, wave-uniform
-    unsigned best = 0u;         // per lane: max of (rank << 3 | class) over its chars
-    int k = 0;
-    while (k < m) {
-        const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
-        const int e = (int)((sb >> 52) & 0x7ff);
-        bool walk = a.fast_ok && e >= a.fast_min_exp && e < 0x7ff;
-        if (walk) {
-            // R_e[c] for the five classes, and whether any addend ties in this binade
-            long long r = 0;
-            bool tie = false;
-            if (lane < 5) {
-                const unsigned long long pb = (unsigned long long)__double_as_longlong(a.class_value[lane]);
-                const int ep = (int)((pb >> 52) & 0x7ff);
-                if (ep != 0) {                                   // zero stays 0 (subnormals excluded by fast_ok)
-                    const unsigned long long mp = (pb & 0xfffffffffffffull) | (1ull << 52);
-                    const int d = e - ep;                        // >= 2 by fast_min_exp
-                    if (d <= 53) {
-                        const unsigned long long half = 1ull << (d - 1);
-                        tie = (mp & ((half << 1) - 1)) == half;
-                        const long long mag = (long long)((mp + half) >> d);
-                        r = (pb >> 63) ? -mag : mag;
+    double s = 0.0;                 // running sum (meaningful in wave 0), wave-uniform
+    unsigned long long key = 0ull;  // per thread: max of (rank << 32 | ~i): best rank, then lowest i
+
+    for (int c0 = 0; c0 < m; c0 += kRescoreChunk) {
+        const int c1 = c0 + kRescoreChunk < m ? c0 + kRescoreChunk : m;
+        // ---- classify the chunk (all waves): four chars per thread and step, several steps in flight
+        {
+            const int groups = (c1 - c0 + 64 * kRescoreEpl + 3) >> 2;
+#pragma unroll 4
+            for (int g = tid; g < groups; g += kRescoreThreads) {
+                const int i = c0 + 4 * g;                         // c0 and the Seq2 code buffer are 4-byte aligned
+                const unsigned w2 = *reinterpret_cast<const unsigned*>(a.s2 + i);   // both buffers are padded with
+                unsigned w1;                                                           // kCodePad (class 4, rank 0)
+                __builtin_memcpy(&w1, s1 + i, 4);
+                unsigned packed = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    unsigned cr = 4u;
+                    if (i + j < c1) {
+                        cr = s_clsrank[((w2 >> (8 * j)) & 0xffu) * kRow + ((w1 >> (8 * j)) & 0xffu)];
+                        const unsigned long long k2 = ((unsigned long long)(cr >> 3) << 32) | (0xffffffffu - (unsigned)(i + j));
+                        key = k2 > key ? k2 : key;
+                    }
+                    packed |= cr << (8 * j);
+                }
+                *reinterpret_cast<unsigned*>(s_codes + 4 * g) = packed;
+            }
+        }
+        __syncthreads();
+        // ---- sum the chunk in reference order (wave 0)
+        if (tid < 64) {
+            int k = c0;
+            while (k < c1) {
+                const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
+                const int e = (int)((sb >> 52) & 0x7ff);
+                bool walk = a.fast_ok && e >= a.fast_min_exp && e < 0x7ff;
+                if (walk) {
+                    // R_e[c] for the five classes, and whether any addend ties in this binade
+                    long long r = 0;
+                    bool tie = false;
+                    if (lane < 5) {
+                        const unsigned long long pb = (unsigned long long)__double_as_longlong(a.class_value[lane]);
+                        const int ep = (int)((pb >> 52) & 0x7ff);
+                        if (ep != 0) {                           // zero stays 0 (subnormals excluded by fast_ok)
+                            const unsigned long long mp = (pb & 0xfffffffffffffull) | (1ull << 52);
+                            const int d = e - ep;                // >= 2 by fast_min_exp
+                            if (d <= 53) {
+                                const unsigned long long half = 1ull << (d - 1);
+                                tie = (mp & ((half << 1) - 1)) == half;
+                                const long long mag = (long long)((mp + half) >> d);
+                                r = (pb >> 63) ? -mag : mag;
+                            }
+                        }
+                        s_round[lane] = r;
+                    }
+                    if (__ballot(tie) != 0ull) walk = false;
+                }
+                if (!walk) {
+                    // plain chain over the next <= 64 chars; lanes past the chunk hold +0.0 (exact to add)
+                    const int nb = c1 - k < 64 ? c1 - k : 64;
+                    s_vals[lane] = lane < nb ? a.class_value[s_codes[k - c0 + lane] & 7u] : 0.0;
+                    __builtin_amdgcn_wave_barrier();
+                    const double2* v = reinterpret_cast<const double2*>(s_vals);   // same address in every lane: broadcast
+#pragma unroll
+                    for (int l = 0; l < 32; ++l) {
+                        const double2 x = v[l];
+                        s += x.x;                                 // reference order (cpu_funcs.c:278)
+                        s += x.y;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    k += nb;
+                    continue;
+                }
+                // integer walk inside binade e
+                __builtin_amdgcn_wave_barrier();
+                long long S = (long long)((sb & 0xfffffffffffffull) | (1ull << 52));
+                const bool neg = (sb >> 63) != 0;
+                if (neg) S = -S;
+                const long long lo = 1ll << 52, hi = 1ll << 53;
+                bool left = false;
+                while (k < c1 && !left) {
+                    const unsigned char* codes = s_codes + (k - c0) + lane * kRescoreEpl;
+                    long long rr[kRescoreEpl];
+                    long long t = 0;
+#pragma unroll
+                    for (int j = 0; j < kRescoreEpl; ++j) {
+                        unsigned cls = codes[j] & 7u;
+                        if (k + lane * kRescoreEpl + j >= c1) cls = 4u;     // the next chunk's chars are not staged yet
+                        rr[j] = s_round[cls];
+                        t += rr[j];
+                    }
+                    const long long incl = wave_scan_inclusive(t);
+                    long long q = S + (incl - t);                 // sum before this lane's first char
+                    long long before[kRescoreEpl];
+                    int bad = kRescoreEpl;
+#pragma unroll
+                    for (int j = 0; j < kRescoreEpl; ++j) {
+                        before[j] = q;
+                        q += rr[j];
+                        const long long mag = neg ? -q : q;
+                        if (!(mag > lo && mag < hi) && bad == kRescoreEpl) bad = j;
+                    }
+                    const unsigned long long bad_lanes = __ballot(bad < kRescoreEpl);
+                    if (bad_lanes == 0ull) {
+                        S = readlane64(q, 63);
+                        const int nb = c1 - k < 64 * kRescoreEpl ? c1 - k : 64 * kRescoreEpl;
+                        k += nb;
+                    } else {
+                        const int L = __ffsll((long long)bad_lanes) - 1;
+                        const int j = __builtin_amdgcn_readlane(bad, L);
+                        long long prev = before[0];
+#pragma unroll
+                        for (int jj = 1; jj < kRescoreEpl; ++jj) prev = jj == j ? before[jj] : prev;
+                        S = readlane64(prev, L);                  // the sum before the char that leaves the binade
+                        k += L * kRescoreEpl + j;
+                        left = true;
                     }
                 }
-                s_round[lane] = r;
-            }
-            if (__ballot(tie) != 0ull) walk = false;
-        }
-        if (!walk) {
-            // plain chain over the next <= 64 chars
-            const int nb = m - k < 64 ? m - k : 64;
-            double p = 0.0;
-            if (lane < nb) {
-                const unsigned cr = s_clsrank[(unsigned)a.s2[k + lane] * kRow + s1[k + lane]];
-                best = cr > best ? cr : best;
-                p = a.class_value[cr & 7u];
-            }
-            s_vals[lane] = p;                                     // lanes past the end hold +0.0: adding it is exact
-            __builtin_amdgcn_wave_barrier();
-            const double2* v = reinterpret_cast<const double2*>(s_vals);   // same address in every lane: broadcast
-#pragma unroll
-            for (int l = 0; l < 32; ++l) {
-                const double2 x = v[l];
-                s += x.x;                                         // reference order (cpu_funcs.c:278)
-                s += x.y;
-            }
-            __builtin_amdgcn_wave_barrier();
-            k += nb;
-            continue;
-        }
-        // integer walk inside binade e
-        __builtin_amdgcn_wave_barrier();
-        long long S = (long long)((sb & 0xfffffffffffffull) | (1ull << 52));
-        const bool neg = (sb >> 63) != 0;
-        if (neg) S = -S;
-        const long long lo = 1ll << 52, hi = 1ll << 53;
-        bool left = false;
-        while (k < m && !left) {
-            const int base = k + lane * kRescoreEpl;
-            long long rr[kRescoreEpl];
-            long long t = 0;
-#pragma unroll
-            for (int j = 0; j < kRescoreEpl; ++j) {
-                unsigned cls = 4u;
-                if (base + j < m) {
-                    const unsigned cr = s_clsrank[(unsigned)a.s2[base + j] * kRow + s1[base + j]];
-                    best = cr > best ? cr : best;
-                    cls = cr & 7u;
+                const unsigned long long mag = (unsigned long long)(S < 0 ? -S : S);
+                s = __longlong_as_double((long long)((neg ? (1ull << 63) : 0ull) | ((unsigned long long)e << 52) |
+                                                     (mag & 0xfffffffffffffull)));
+                if (left) {
+                    // this char moves the sum out of the binade: one true fp64 add
+                    s += a.class_value[s_codes[k - c0] & 7u];
+                    k += 1;
                 }
-                rr[j] = s_round[cls];
-                t += rr[j];
-            }
-            const long long incl = wave_scan_inclusive(t, lane);
-            long long q = S + (incl - t);                 // sum before this lane's first char
-            long long before[kRescoreEpl];
-            int bad = kRescoreEpl;
-#pragma unroll
-            for (int j = kRescoreEpl - 1; j >= 0; --j) before[j] = 0;
-#pragma unroll
-            for (int j = 0; j < kRescoreEpl; ++j) {
-                before[j] = q;
-                q += rr[j];
-                const long long mag = neg ? -q : q;
-                if (!(mag > lo && mag < hi) && bad == kRescoreEpl) bad = j;
-            }
-            const unsigned long long bad_lanes = __ballot(bad < kRescoreEpl);
-            if (bad_lanes == 0ull) {
-                S = __shfl(q, 63, 64);
-                const int nb = m - k < 64 * kRescoreEpl ? m - k : 64 * kRescoreEpl;
-                k += nb;
-            } else {
-                const int L = __ffsll((long long)bad_lanes) - 1;
-                const int j = __shfl(bad, L, 64);
-                long long prev = before[0];
-#pragma unroll
-                for (int jj = 1; jj < kRescoreEpl; ++jj) prev = jj == j ? before[jj] : prev;
-                S = __shfl(prev, L, 64);                  // the sum before the char that leaves the binade
-                k += L * kRescoreEpl + j;
-                left = true;
+                __builtin_amdgcn_wave_barrier();
             }
         }
-        const unsigned long long mag = (unsigned long long)(S < 0 ? -S : S);
-        s = __longlong_as_double((long long)((neg ? (1ull << 63) : 0ull) | ((unsigned long long)e << 52) |
-                                             (mag & 0xfffffffffffffull)));
-        if (left) {
-            // this char moves the sum out of the binade: one true fp64 add (its class was
-            // already folded into `best` by the lane that owned it)
-            const unsigned cr = s_clsrank[(unsigned)a.s2[k] * kRow + s1[k]];
-            s += a.class_value[cr & 7u];
-            k += 1;
-        }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();            // the next chunk overwrites s_codes
     }
+
+    // best rank and its first position over all chars
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned other = __shfl_xor(best, d, 64);
-        best = other > best ? other : best;
+        const unsigned long long other = __shfl_xor(key, d, 64);
+        key = other > key ? other : key;
     }
-    if (lane == 0) {
-        const int rank = (int)(best >> 3);
-        BlockRec r;
-        r.score = rank ? s + a.delta_of_rank[rank] : a.delta_of_rank[0];
+    if (lane == 0) s_key[tid >> 6] = key;
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < kRescoreThreads / 64; ++w) key = s_key[w] > key ? s_key[w] : key;
+        const int rank = (int)(key >> 32);
+        CandRec r;
         r.offset = o;
         r.rank = rank;
+        if (rank) {
+            const int i = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+            r.score = s + a.delta_of_rank[rank];
+            r.char_offset = i;
+            r.ch = a.sub[(unsigned)a.s2[i] * kRow + s1[i]];
+        } else {
+            r.score = a.delta_of_rank[0];
+            r.char_offset = -1;
+            r.ch = 0;
+        }
         a.rec[blockIdx.x] = r;
     }
-}
-
-// ---- final fold of the candidate records (is_swapable order) + the winner's substitution
-struct FoldArgs {
-    const BlockRec*      rec;
-    const int*           cand_count;
-    const unsigned char* s1;
-    const unsigned char* s2;        // byte codes
-    const unsigned char* rank;      // [32][32]
-    const unsigned char* sub;
-    psa_result*          out;
-    int*                 overflow;  // set when the candidate list did not fit
-    int m;
-    int cap;
-    int is_max;
-    long long pairs;
-};
-
-__global__ __launch_bounds__(256) void psa_fold_kernel(FoldArgs a)
-{
-    __shared__ BlockRec s_fold[4];
-    __shared__ BlockRec s_win;
-    __shared__ int s_first_i;
-    const bool is_max = a.is_max != 0;
-    int count = *a.cand_count;
-    if (threadIdx.x == 0) *a.overflow = count > a.cap ? 1 : 0;
-    if (count > a.cap) count = a.cap;
-    double s = is_max ? -INFINITY : INFINITY;
-    int o = INT_MAX, r = 0;
-    for (int k = threadIdx.x; k < count; k += 256) {
-        const BlockRec b = a.rec[k];
-        if (rec_better(is_max, b.score, b.offset, s, o)) { s = b.score; o = b.offset; r = b.rank; }
-    }
-    block_fold(is_max, s, o, r, s_fold);
-    if (threadIdx.x == 0) {
-        s_win.score = s; s_win.offset = o; s_win.rank = r;
-        s_first_i = INT_MAX;
-    }
-    __syncthreads();
-    const BlockRec w = s_win;
-    if (w.offset == INT_MAX || w.rank == 0) {
-        if (threadIdx.x == 0) {
-            a.out->score = is_max ? -INFINITY : INFINITY;
-            a.out->offset = -1;
-            a.out->char_offset = -1;
-            a.out->ch = 0;
-            a.out->shard = -1;
-            a.out->pairs = a.pairs;
+    // ---- the last candidate workgroup to finish folds all records (is_swapable order).
+    // Hand-off per the release/acquire rule: record store -> agent-scope release ->
+    // relaxed atomic arrival; the last arriver acquires before reading the records.
+    __shared__ int s_last;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int arrived = __hip_atomic_fetch_add(a.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = arrived == count - 1;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        return;
     }
-    // first char whose delta rank is the offset's best (cpu_funcs.c:287-294: strict compare keeps the lowest i)
-    int mine = INT_MAX;
-    for (int i = threadIdx.x; i < a.m; i += 256) {
-        const unsigned idx = (unsigned)a.s2[i] * kRow + a.s1[w.offset + i];
-        if (a.rank[idx] == w.rank) { mine = i; break; }
-    }
-    atomicMin(&s_first_i, mine);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int i = s_first_i;
-        const unsigned idx = (unsigned)a.s2[i] * kRow + a.s1[w.offset + i];
-        a.out->score = w.score;
-        a.out->offset = w.offset;
-        a.out->char_offset = i;
-        a.out->ch = a.sub[idx];
-        a.out->shard = -1;
-        a.out->pairs = a.pairs;
+    if (!s_last || tid >= 64) return;
+    {
+        const bool is_max = a.is_max != 0;
+        const int total = *a.cand_count;
+        double bs = is_max ? -INFINITY : INFINITY;
+        int bo = INT_MAX, idx = -1;
+        for (int k = lane; k < count; k += 64) {
+            const CandRec b = a.rec[k];
+            if (b.rank != 0 && rec_better(is_max, b.score, b.offset, bs, bo)) { bs = b.score; bo = b.offset; idx = k; }
+        }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const double s2 = __shfl_xor(bs, d, 64);
+            const int o2 = __shfl_xor(bo, d, 64);
+            const int i2 = __shfl_xor(idx, d, 64);
+            if (rec_better(is_max, s2, o2, bs, bo)) { bs = s2; bo = o2; idx = i2; }
+        }
+        if (lane == 0) {
+            psa_result r;
+            if (idx >= 0) {
+                const CandRec b = a.rec[idx];
+                r.score = b.score;
+                r.offset = b.offset;
+                r.char_offset = b.char_offset;
+                r.ch = b.ch;
+            } else {
+                r.score = is_max ? -INFINITY : INFINITY;
+                r.offset = -1;
+                r.char_offset = -1;
+                r.ch = 0;
+            }
+            r.shard = -1;
+            r.pairs = a.pairs;
+            a.out->result = r;
+            a.out->bad = *a.bad;
+            a.out->overflow = total > a.cap ? 1 : 0;
+        }
     }
 }
 
