@@ -103,6 +103,18 @@ psa_status psa_search(psa_context* ctx, int first_offset, int last_offset, psa_r
 psa_status psa_search_async(psa_context* ctx, int first_offset, int last_offset);
 psa_status psa_search_wait(psa_context* ctx, psa_result* out);
 
+/* Batch of nq queries (BASELINE.json configs[4]): nq Seq2 sequences of m characters
+ * each, `stride` bytes apart in one buffer (host memory for psa_search_batch, device
+ * memory for psa_search_batch_device), all searched over offsets [first,last) of the
+ * context's Seq1 with its weights and mode.  results[q] (host memory, shard = q) is
+ * what psa_search would return for query q.  Blocking.  Inside the call, query q+1's
+ * scoring kernel overlaps query q's candidate re-score and read-back on a second
+ * stream.  Replaces the Seq2 set by psa_set_seq2*. */
+psa_status psa_search_batch(psa_context* ctx, const char* queries, int nq, int m, size_t stride,
+                            int first_offset, int last_offset, psa_result* results);
+psa_status psa_search_batch_device(psa_context* ctx, const void* d_queries, int nq, int m, size_t stride,
+                                   int first_offset, int last_offset, psa_result* results);
+
 /* Per-offset view for tests: scores[o-first] = total+diff of offset o,
  * char_offsets / chs the chosen substitution (find_best_mutant_offset,
  * cpu_funcs.c:257-300).  Arrays are host memory of last-first entries; any

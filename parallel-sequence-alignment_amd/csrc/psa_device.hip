@@ -296,12 +296,19 @@ using psa::set_last_error;
         }                                                                                      \
     } while (0)
 
+#define PSA_TRY(expr)                                                                          \
+    do {                                                                                       \
+        psa_status st_ = (expr);                                                               \
+        if (st_ != PSA_OK) return st_;                                                         \
+    } while (0)
+
 namespace {
 
 constexpr int kLdsLimit = 160 * 1024;
 constexpr int kCandCap = 2048;        // candidates re-scored per search before falling back
 constexpr int kSeq1Slack = 49152;     // code-27 tail behind Seq1: tile + chunk rounding + staged-window over-read
 constexpr int kSeq2Slack = 32768 + 64;
+constexpr int kSlots = 2;             // searches in flight inside a batch
 
 struct Scalars {                      // small device-side state of one filter search
     int cand_count;
@@ -328,42 +335,52 @@ psa_status dev_alloc(T** ptr, size_t count)
     return PSA_OK;
 }
 
+// Everything one search writes.  The single-search API uses slot 0; a batch
+// alternates between the slots so the tail of query q (re-score, read-back)
+// overlaps the count kernel of query q+1.
+struct SearchSlot {
+    int m = -1, m_cap = 0;
+    unsigned int*       d_s2rows = nullptr;    // Seq2 codes as u32 (sequential engine: scalar loads)
+    unsigned char*      d_s2bytes = nullptr;   // Seq2 codes as bytes (filter engine)
+    psa::BlockRec*      d_blocks = nullptr;    int blocks_cap = 0;      // sequential engine
+    unsigned long long* d_partial = nullptr;   size_t partial_cap = 0;
+    double*             d_upper = nullptr;     size_t upper_cap = 0;
+    unsigned long long* d_block_best = nullptr; int block_best_cap = 0;
+    Scalars*            d_scal = nullptr;
+    int*                d_cand = nullptr;
+    psa::CandRec*       d_rec = nullptr;
+    psa::SearchTail*    d_tail = nullptr;
+    hipEvent_t          front_done = nullptr;  // count + select enqueued
+    hipEvent_t          back_done = nullptr;   // re-score + read-back enqueued
+};
+
 }  // namespace
 
 struct psa_context {
     int         device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;      // main stream (caller's or owned)
+    hipStream_t aux = nullptr;         // owned: tails of batched searches
     bool        own_stream = false;
 
     psa::Tables tables;
     bool        have_weights = false;
-    int         n = -1, m = -1;
-    int         n_cap = 0, m_cap = 0;        // allocated code capacities
+    int         n = -1;
+    int         n_cap = 0;
 
     unsigned char* d_raw = nullptr;  size_t raw_cap = 0;   // staging for host sequences
     unsigned char* d_s1 = nullptr;        // Seq1 codes, code-27 padded to n_cap
-    unsigned int*  d_s2rows = nullptr;    // Seq2 codes as u32 (sequential engine: scalar loads)
-    unsigned char* d_s2bytes = nullptr;   // Seq2 codes as bytes (filter engine)
+    uint2*         d_masks = nullptr;     int nslots = 0;   // Seq1 class planes
     double*        d_pair = nullptr;
     unsigned char* d_rank = nullptr;
     unsigned char* d_sub = nullptr;
     double*        d_delta = nullptr;
-    unsigned*      d_letter_masks = nullptr;
+    unsigned*      d_symbol_planes = nullptr;
     unsigned char* d_clsrank = nullptr;   // class | rank << 3 per pair (rescore kernel)
-    psa::BlockRec* d_blocks = nullptr;  int blocks_cap = 0;
-    psa::SearchTail* d_tail = nullptr;
-    psa::SearchTail* h_tail = nullptr;   // pinned
     int*           d_bad = nullptr;
-    int*           h_bad = nullptr;      // pinned
+    int*           h_bad = nullptr;       // pinned
+    psa::SearchTail* h_tails = nullptr;   int tails_cap = 0;     // pinned, one per query of a batch (>= 1)
 
-    // filter engine
-    uint2*              d_masks = nullptr;   int nslots = 0;
-    unsigned long long* d_partial = nullptr; size_t partial_cap = 0;
-    double*             d_upper = nullptr;   size_t upper_cap = 0;
-    Scalars*            d_scal = nullptr;
-    int*                d_cand = nullptr;
-    psa::CandRec*       d_rec = nullptr;
-    unsigned long long* d_block_best = nullptr;   int block_best_cap = 0;
+    SearchSlot  slot[kSlots];
 
     psa_engine  engine = PSA_ENGINE_AUTO;
     int         forced_r = 0;
@@ -403,7 +420,7 @@ psa_status upload_tables(psa_context* c)
 }
 
 // Reads the encode kernels' flag.  Blocking; used by the host-sequence setters
-// (device-sequence setters defer the check to psa_search_wait).
+// (device-sequence setters defer the check to the end of the search).
 psa_status check_bad_now(psa_context* c)
 {
     PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -418,7 +435,7 @@ psa_status report_bad(psa_context* c)
     PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
     *c->h_bad = 0;
     if (bad & 1) c->n = -1;
-    if (bad & 2) c->m = -1;
+    if (bad & 2) for (auto& s : c->slot) s.m = -1;
     set_last_error(std::string(bad & 1 ? "seq1" : "seq2") + " contains a character outside [A-Z-]");
     return PSA_ERR_ALPHABET;
 }
@@ -429,19 +446,17 @@ psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
 {
     const int need = (n + kSeq1Slack + 63) & ~63;
     if (need > c->n_cap) {
-        psa_status st = dev_alloc(&c->d_s1, (size_t)need);
-        if (st != PSA_OK) return st;
+        PSA_TRY(dev_alloc(&c->d_s1, (size_t)need));
         c->n_cap = need;
         c->nslots = need / 32;
-        st = dev_alloc(&c->d_masks, (size_t)psa::kMaskRows * c->nslots);
-        if (st != PSA_OK) return st;
+        PSA_TRY(dev_alloc(&c->d_masks, (size_t)psa::kMaskRows * c->nslots));
     }
     c->n = -1;
     psa::PrepareArgs a;
     a.raw = static_cast<const unsigned char*>(d_raw);
     a.codes = c->d_s1;
     a.masks = c->d_masks;
-    a.symbol_planes = c->d_letter_masks;
+    a.symbol_planes = c->d_symbol_planes;
     a.bad = c->d_bad;
     a.n = n;
     a.nslots = c->nslots;
@@ -451,32 +466,41 @@ psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
     return PSA_OK;
 }
 
-psa_status encode_seq2(psa_context* c, const void* d_raw, int m)
+psa_status encode_seq2(psa_context* c, SearchSlot& s, const void* d_raw, int m, hipStream_t stream)
 {
     const int need = (m + kSeq2Slack + 63) & ~63;
-    if (need > c->m_cap) {
-        psa_status st = dev_alloc(&c->d_s2rows, (size_t)need);
-        if (st != PSA_OK) return st;
-        st = dev_alloc(&c->d_s2bytes, (size_t)need);
-        if (st != PSA_OK) return st;
-        c->m_cap = need;
+    if (need > s.m_cap) {
+        PSA_TRY(dev_alloc(&s.d_s2rows, (size_t)need));
+        PSA_TRY(dev_alloc(&s.d_s2bytes, (size_t)need));
+        s.m_cap = need;
     }
-    c->m = -1;
-    hipLaunchKernelGGL(psa::psa_encode_seq2, dim3((c->m_cap + 255) / 256), dim3(256), 0, c->stream,
-                       static_cast<const unsigned char*>(d_raw), m, c->d_s2rows, c->d_s2bytes, c->m_cap, c->d_bad);
+    s.m = -1;
+    hipLaunchKernelGGL(psa::psa_encode_seq2, dim3((s.m_cap + 255) / 256), dim3(256), 0, stream,
+                       static_cast<const unsigned char*>(d_raw), m, s.d_s2rows, s.d_s2bytes, s.m_cap, c->d_bad);
     PSA_HIP(hipGetLastError());
-    c->m = m;
+    s.m = m;
     return PSA_OK;
 }
 
-psa_status stage_host(psa_context* c, const char* host, int len)
+psa_status stage_host(psa_context* c, const char* host, size_t len)
 {
-    if ((size_t)len > c->raw_cap) {
-        psa_status st = dev_alloc(&c->d_raw, (size_t)len + 64);
-        if (st != PSA_OK) { c->raw_cap = 0; return st; }
-        c->raw_cap = (size_t)len + 64;
+    if (len > c->raw_cap) {
+        c->raw_cap = 0;
+        PSA_TRY(dev_alloc(&c->d_raw, len + 64));
+        c->raw_cap = len + 64;
     }
     PSA_HIP(hipMemcpyAsync(c->d_raw, host, len, hipMemcpyHostToDevice, c->stream));
+    return PSA_OK;
+}
+
+psa_status ensure_tails(psa_context* c, int count)
+{
+    if (count <= c->tails_cap) return PSA_OK;
+    if (c->h_tails) PSA_HIP(hipHostFree(c->h_tails));
+    c->h_tails = nullptr;
+    c->tails_cap = 0;
+    PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_tails), sizeof(psa::SearchTail) * (size_t)count, hipHostMallocDefault));
+    c->tails_cap = count;
     return PSA_OK;
 }
 
@@ -489,65 +513,66 @@ int pick_r(const psa_context* c, int span)
     return 1;
 }
 
-psa_status launch_sequential(psa_context* c, int first, int last, double* per_score, unsigned char* per_rank)
+psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last, double* per_score,
+                             unsigned char* per_rank, hipStream_t stream)
 {
     const int span = last - first;
     const int r = pick_r(c, span);
     const int base = first & ~3;
     const int lanes = (last - base + r - 1) / r;
     const int nblocks = (lanes + psa::kBlock - 1) / psa::kBlock;
-    if (nblocks > c->blocks_cap) {
-        psa_status st = dev_alloc(&c->d_blocks, (size_t)nblocks);
-        if (st != PSA_OK) { c->blocks_cap = 0; return st; }
-        c->blocks_cap = nblocks;
+    if (nblocks > s.blocks_cap) {
+        s.blocks_cap = 0;
+        PSA_TRY(dev_alloc(&s.d_blocks, (size_t)nblocks));
+        s.blocks_cap = nblocks;
     }
     psa::SeqArgs a;
     a.s1 = c->d_s1;
-    a.s2rows = c->d_s2rows;
+    a.s2rows = s.d_s2rows;
     a.pair = c->d_pair;
     a.rank = c->d_rank;
     a.delta_of_rank = c->d_delta;
-    a.block_out = c->d_blocks;
+    a.block_out = s.d_blocks;
     a.per_score = per_score;
     a.per_rank = per_rank;
-    a.m = c->m;
-    a.m4 = (c->m + 3) & ~3;
+    a.m = s.m;
+    a.m4 = (s.m + 3) & ~3;
     a.first = first;
     a.last = last;
     a.base = base;
     a.is_max = c->tables.is_max;
 
-    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[2], c->stream));
+    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[2], stream));
     switch (r) {
     case 4:
-        hipLaunchKernelGGL(psa::psa_seq_kernel<4>, dim3(nblocks), dim3(psa::kBlock), 0, c->stream, a);
+        hipLaunchKernelGGL(psa::psa_seq_kernel<4>, dim3(nblocks), dim3(psa::kBlock), 0, stream, a);
         c->last_kernel = "psa_seq_kernel<4>";
         break;
     case 2:
-        hipLaunchKernelGGL(psa::psa_seq_kernel<2>, dim3(nblocks), dim3(psa::kBlock), 0, c->stream, a);
+        hipLaunchKernelGGL(psa::psa_seq_kernel<2>, dim3(nblocks), dim3(psa::kBlock), 0, stream, a);
         c->last_kernel = "psa_seq_kernel<2>";
         break;
     default:
-        hipLaunchKernelGGL(psa::psa_seq_kernel<1>, dim3(nblocks), dim3(psa::kBlock), 0, c->stream, a);
+        hipLaunchKernelGGL(psa::psa_seq_kernel<1>, dim3(nblocks), dim3(psa::kBlock), 0, stream, a);
         c->last_kernel = "psa_seq_kernel<1>";
         break;
     }
     PSA_HIP(hipGetLastError());
-    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[3], c->stream));
+    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[3], stream));
 
     psa::FinalArgs f;
-    f.block_in = c->d_blocks;
+    f.block_in = s.d_blocks;
     f.nblocks = nblocks;
     f.s1 = c->d_s1;
-    f.s2rows = c->d_s2rows;
+    f.s2rows = s.d_s2rows;
     f.rank = c->d_rank;
     f.sub = c->d_sub;
-    f.out = c->d_tail;
+    f.out = s.d_tail;
     f.bad = c->d_bad;
-    f.m = c->m;
+    f.m = s.m;
     f.is_max = c->tables.is_max;
-    f.pairs = (long long)span * (long long)c->m;
-    hipLaunchKernelGGL(psa::psa_finalize_kernel, dim3(1), dim3(psa::kBlock), 0, c->stream, f);
+    f.pairs = (long long)span * (long long)s.m;
+    hipLaunchKernelGGL(psa::psa_finalize_kernel, dim3(1), dim3(psa::kBlock), 0, stream, f);
     PSA_HIP(hipGetLastError());
     return PSA_OK;
 }
@@ -555,7 +580,7 @@ psa_status launch_sequential(psa_context* c, int first, int last, double* per_sc
 // ---- filter engine -------------------------------------------------------------
 int exchange_bytes(int waves)
 {
-    // round 0 of the epilogue: waves/2 writers, 6*kPlanes+2 dwords per lane
+    // round 0 of the epilogue: waves/2 writers, 2*kCounters*kPlanes dwords per lane
     return (waves / 2) * (2 * psa::kCounters * psa::kPlanes) * 64 * 4;
 }
 
@@ -607,7 +632,7 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
     return found;
 }
 
-double filter_slack(const psa_context* c)
+double filter_slack(const psa_context* c, int m)
 {
     // |sequential fp64 sum - exact sum| <= (m-1) u sum|p_i| / (1 - (m-1) u)   (u = 2^-53),
     // the count formula and the "+ delta" add a handful of roundings more.
@@ -616,13 +641,11 @@ double filter_slack(const psa_context* c)
     for (int k = 0; k < 4; ++k) wmax = std::fmax(wmax, std::fabs(c->tables.weights[k]));
     for (int r = 1; r <= c->tables.nranks; ++r) dmax = std::fmax(dmax, std::fabs(c->tables.delta_of_rank[r]));
     const double u = 1.1102230246251565e-16;
-    const double mag = (double)c->m * wmax + dmax;
-    return 2.0 * 1.05 * ((double)c->m + 32.0) * u * mag;
+    const double mag = (double)m * wmax + dmax;
+    return 2.0 * 1.05 * ((double)m + 32.0) * u * mag;
 }
 
-double filter_slack(const psa_context* c);
-
-psa::BoundParams bound_params(const psa_context* c)
+psa::BoundParams bound_params(const psa_context* c, int m)
 {
     const psa::Tables& t = c->tables;
     psa::BoundParams b;
@@ -631,62 +654,131 @@ psa::BoundParams bound_params(const psa_context* c)
         b.class_best[i] = t.class_best_delta[i];
         b.class_worst[i] = t.class_worst_delta[i];
     }
-    b.slack = filter_slack(c);
-    b.m = c->m;
+    b.slack = filter_slack(c, m);
+    b.m = m;
     b.is_max = t.is_max;
     return b;
 }
 
 // first/span describe the searched range when the kernel should also produce the score
 // bounds (single-chunk plans); span = 0 writes raw partial counts instead.
-psa_status launch_count(psa_context* c, const FilterPlan& p, int base, int span_pad, int first, int span)
+psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int base, int span_pad, int first,
+                        int span, hipStream_t stream)
 {
     psa::CountArgs a;
     a.masks = c->d_masks;
-    a.s2 = c->d_s2bytes;
-    a.partial = c->d_partial;
+    a.s2 = s.d_s2bytes;
+    a.partial = s.d_partial;
     a.nslots = c->nslots;
     a.base = base;
     a.span_pad = span_pad;
     a.chunk_chars = p.chunk_chars;
     a.wave_chars = p.wave_chars;
     a.lds_slots = p.lds_slots;
-    a.zero = &c->d_scal->cand_count;      // the search scalars: cleared here for the kernels behind this one
-    a.upper = span > 0 ? c->d_upper : nullptr;
-    a.block_best = c->d_block_best;
+    a.zero = &s.d_scal->cand_count;      // the search scalars: cleared here for the kernels behind this one
+    a.upper = span > 0 ? s.d_upper : nullptr;
+    a.block_best = s.d_block_best;
     a.lead = first - base;
     a.span = span;
-    a.bounds = bound_params(c);
+    a.bounds = bound_params(c, s.m);
     const dim3 grid(p.ntiles, p.nchunks);
     if (p.waves == 16) {
         PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_bytes));
-        hipLaunchKernelGGL(psa::psa_count_kernel<16>, grid, dim3(16 * 64), p.lds_bytes, c->stream, a);
+        hipLaunchKernelGGL(psa::psa_count_kernel<16>, grid, dim3(16 * 64), p.lds_bytes, stream, a);
         c->last_kernel = "psa_count_kernel<16>";
     } else {
         PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<8>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_bytes));
-        hipLaunchKernelGGL(psa::psa_count_kernel<8>, grid, dim3(8 * 64), p.lds_bytes, c->stream, a);
+        hipLaunchKernelGGL(psa::psa_count_kernel<8>, grid, dim3(8 * 64), p.lds_bytes, stream, a);
         c->last_kernel = "psa_count_kernel<8>";
     }
     PSA_HIP(hipGetLastError());
     return PSA_OK;
 }
 
-psa_status launch_rescore(psa_context* c, long long pairs)
+// count (+ bounds) and candidate selection
+psa_status launch_filter_front(psa_context* c, SearchSlot& s, int first, int last, hipStream_t stream, bool profile)
+{
+    const int span = last - first;
+    const int base = first & ~31;
+    FilterPlan p;
+    if (!plan_filter(first, last, s.m, &p)) {
+        set_last_error("internal: no filter plan fits the LDS");
+        return PSA_ERR_ARG;
+    }
+    const int span_pad = p.ntiles * psa::kTile;
+    const bool inline_keys = p.nchunks == 1;
+    if (!inline_keys) {
+        const size_t need_partial = (size_t)p.nchunks * span_pad;
+        if (need_partial > s.partial_cap) {
+            s.partial_cap = 0;
+            PSA_TRY(dev_alloc(&s.d_partial, need_partial));
+            s.partial_cap = need_partial;
+        }
+    }
+    if ((size_t)span > s.upper_cap) {
+        s.upper_cap = 0;
+        PSA_TRY(dev_alloc(&s.d_upper, (size_t)span));
+        s.upper_cap = (size_t)span;
+    }
+    const int need_best = std::max(p.ntiles, psa::kKeyBlocks);
+    if (need_best > s.block_best_cap) {
+        s.block_best_cap = 0;
+        PSA_TRY(dev_alloc(&s.d_block_best, (size_t)need_best));
+        s.block_best_cap = need_best;
+    }
+
+    if (profile) PSA_HIP(hipEventRecord(c->ev[2], stream));
+    PSA_TRY(launch_count(c, s, p, base, span_pad, first, inline_keys ? span : 0, stream));
+    if (profile) PSA_HIP(hipEventRecord(c->ev[3], stream));
+
+    int nbest = p.ntiles;
+    if (!inline_keys) {
+        psa::KeyArgs k;
+        k.partial = s.d_partial;
+        k.upper = s.d_upper;
+        k.block_best = s.d_block_best;
+        k.bounds = bound_params(c, s.m);
+        k.nchunks = p.nchunks;
+        k.span_pad = span_pad;
+        k.span = span;
+        k.lead = first - base;
+        nbest = std::min(psa::kKeyBlocks, (span + 255) / 256);
+        hipLaunchKernelGGL(psa::psa_keys_kernel, dim3(nbest), dim3(256), 0, stream, k);
+        PSA_HIP(hipGetLastError());
+    }
+
+    psa::SelectArgs sel;
+    sel.upper = s.d_upper;
+    sel.block_best = s.d_block_best;
+    sel.nbest = nbest;
+    sel.cand = s.d_cand;
+    sel.cand_count = &s.d_scal->cand_count;
+    sel.span = span;
+    sel.first = first;
+    sel.cap = kCandCap;
+    hipLaunchKernelGGL(psa::psa_select_kernel, dim3(std::min(psa::kKeyBlocks, (span + 255) / 256)), dim3(256), 0,
+                       stream, sel);
+    PSA_HIP(hipGetLastError());
+    return PSA_OK;
+}
+
+// exact re-score of the candidates + fold into the slot's tail
+psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hipStream_t stream)
 {
     const psa::Tables& t = c->tables;
     psa::RescoreArgs r;
     r.s1 = c->d_s1;
-    r.s2 = c->d_s2bytes;
+    r.s2 = s.d_s2bytes;
     r.clsrank = c->d_clsrank;
     r.sub = c->d_sub;
     r.delta_of_rank = c->d_delta;
-    r.cand = c->d_cand;
-    r.cand_count = &c->d_scal->cand_count;
-    r.rec = c->d_rec;
-    r.done = &c->d_scal->done;
-    r.out = c->d_tail;
+    r.cand = s.d_cand;
+    r.cand_count = &s.d_scal->cand_count;
+    r.rec = s.d_rec;
+    r.done = &s.d_scal->done;
+    r.out = s.d_tail;
     r.bad = c->d_bad;
     r.pairs = pairs;
     r.class_value[0] = t.weights[0];       // get_weight, cuda_funcs.cu:442-452
@@ -694,7 +786,7 @@ psa_status launch_rescore(psa_context* c, long long pairs)
     r.class_value[2] = -t.weights[2];
     r.class_value[3] = -t.weights[3];
     for (int i = 4; i < 8; ++i) r.class_value[i] = 0.0;
-    r.m = c->m;
+    r.m = s.m;
     r.cap = kCandCap;
     r.is_max = t.is_max;
     {
@@ -709,102 +801,32 @@ psa_status launch_rescore(psa_context* c, long long pairs)
             if (e == 0 && (bits << 1) != 0) ok = false;          // subnormal weight
             if (e > max_exp) max_exp = e;
         }
-        r.fast_ok = ok && std::getenv("PSA_RESCORE_CHAIN") == nullptr;
+        static const bool chain_only = std::getenv("PSA_RESCORE_CHAIN") != nullptr;   // experiment knob
+        r.fast_ok = ok && !chain_only;
         r.fast_min_exp = max_exp + 2;
     }
-    hipLaunchKernelGGL(psa::psa_rescore_kernel, dim3(kCandCap), dim3(psa::kRescoreThreads), 0, c->stream, r);
+    hipLaunchKernelGGL(psa::psa_rescore_kernel, dim3(kCandCap), dim3(psa::kRescoreThreads), 0, stream, r);
     PSA_HIP(hipGetLastError());
-
     return PSA_OK;
 }
 
-psa_status launch_filter(psa_context* c, int first, int last)
-{
-    const int span = last - first;
-    const int base = first & ~31;
-    FilterPlan p;
-    if (!plan_filter(first, last, c->m, &p)) {
-        set_last_error("internal: no filter plan fits the LDS");
-        return PSA_ERR_ARG;
-    }
-    const int span_pad = p.ntiles * psa::kTile;
-    const bool inline_keys = p.nchunks == 1;
-    if (!inline_keys) {
-        const size_t need_partial = (size_t)p.nchunks * span_pad;
-        if (need_partial > c->partial_cap) {
-            psa_status st = dev_alloc(&c->d_partial, need_partial);
-            if (st != PSA_OK) { c->partial_cap = 0; return st; }
-            c->partial_cap = need_partial;
-        }
-    }
-    if ((size_t)span > c->upper_cap) {
-        psa_status st = dev_alloc(&c->d_upper, (size_t)span);
-        if (st != PSA_OK) { c->upper_cap = 0; return st; }
-        c->upper_cap = (size_t)span;
-    }
-    if (p.ntiles > c->block_best_cap) {
-        psa_status st = dev_alloc(&c->d_block_best, (size_t)p.ntiles);
-        if (st != PSA_OK) { c->block_best_cap = 0; return st; }
-        c->block_best_cap = p.ntiles;
-    }
-
-    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[2], c->stream));
-    psa_status st = launch_count(c, p, base, span_pad, first, inline_keys ? span : 0);
-    if (st != PSA_OK) return st;
-    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[3], c->stream));
-
-    int nbest = p.ntiles;
-    if (!inline_keys) {
-        psa::KeyArgs k;
-        k.partial = c->d_partial;
-        k.upper = c->d_upper;
-        k.block_best = c->d_block_best;
-        k.bounds = bound_params(c);
-        k.nchunks = p.nchunks;
-        k.span_pad = span_pad;
-        k.span = span;
-        k.lead = first - base;
-        nbest = std::min(psa::kKeyBlocks, (span + 255) / 256);
-        hipLaunchKernelGGL(psa::psa_keys_kernel, dim3(nbest), dim3(256), 0, c->stream, k);
-        PSA_HIP(hipGetLastError());
-    }
-
-    psa::SelectArgs s;
-    s.upper = c->d_upper;
-    s.block_best = c->d_block_best;
-    s.nbest = nbest;
-    s.cand = c->d_cand;
-    s.cand_count = &c->d_scal->cand_count;
-    s.span = span;
-    s.first = first;
-    s.cap = kCandCap;
-    hipLaunchKernelGGL(psa::psa_select_kernel, dim3(std::min(psa::kKeyBlocks, (span + 255) / 256)), dim3(256), 0,
-                       c->stream, s);
-    PSA_HIP(hipGetLastError());
-
-    psa_status rst = launch_rescore(c, (long long)span * (long long)c->m);
-    if (rst != PSA_OK) return rst;
-
-    return PSA_OK;
-}
-
-bool use_filter(const psa_context* c, int first, int last)
+bool use_filter(const psa_context* c, int first, int last, int m)
 {
     if (c->engine == PSA_ENGINE_SEQUENTIAL) return false;
     if (c->engine == PSA_ENGINE_FILTER) return true;
-    // the filter's fixed cost (mask build + 5 small launches) only pays off on big searches
-    return (long long)(last - first) * c->m >= 20000000ll;
+    // the filter's fixed cost (several small launches) only pays off on big searches
+    return (long long)(last - first) * m >= 20000000ll;
 }
 
-psa_status check_ready(psa_context* c, int first, int last)
+psa_status check_ready(psa_context* c, int m, int first, int last)
 {
     if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
-    if (!c->have_weights || c->n < 0 || c->m < 0) {
+    if (!c->have_weights || c->n < 0 || m < 0) {
         set_last_error("weights, seq1 and seq2 must be set before a search");
         return PSA_ERR_STATE;
     }
-    const long long total = (long long)c->n - c->m + 1;
-    if (c->m < 1 || total < 1) {
+    const long long total = (long long)c->n - m + 1;
+    if (m < 1 || total < 1) {
         set_last_error("need 1 <= len(seq2) <= len(seq1)");
         return PSA_ERR_ARG;
     }
@@ -813,6 +835,33 @@ psa_status check_ready(psa_context* c, int first, int last)
         return PSA_ERR_ARG;
     }
     return PSA_OK;
+}
+
+psa_status init_slot(SearchSlot& s)
+{
+    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_scal), sizeof(Scalars)));
+    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_cand), sizeof(int) * kCandCap));
+    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_rec), sizeof(psa::CandRec) * kCandCap));
+    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_tail), sizeof(psa::SearchTail)));
+    PSA_HIP(hipEventCreateWithFlags(&s.front_done, hipEventDisableTiming));
+    PSA_HIP(hipEventCreateWithFlags(&s.back_done, hipEventDisableTiming));
+    return PSA_OK;
+}
+
+void free_slot(SearchSlot& s)
+{
+    (void)hipFree(s.d_s2rows);
+    (void)hipFree(s.d_s2bytes);
+    (void)hipFree(s.d_blocks);
+    (void)hipFree(s.d_partial);
+    (void)hipFree(s.d_upper);
+    (void)hipFree(s.d_block_best);
+    (void)hipFree(s.d_scal);
+    (void)hipFree(s.d_cand);
+    (void)hipFree(s.d_rec);
+    (void)hipFree(s.d_tail);
+    if (s.front_done) (void)hipEventDestroy(s.front_done);
+    if (s.back_done) (void)hipEventDestroy(s.back_done);
 }
 
 }  // namespace
@@ -839,11 +888,19 @@ psa_status psa_create(int device, void* stream, psa_context** out)
             PSA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
             c->own_stream = true;
         }
+        PSA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_pair), sizeof(double) * psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_rank), psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_sub), psa::kRow * psa::kRow));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_clsrank), psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_delta), sizeof(double) * psa::kMaxRanks));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_letter_masks), sizeof(unsigned) * 64));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_symbol_planes), sizeof(unsigned) * 64));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bad), sizeof(int)));
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_bad), sizeof(int), hipHostMallocDefault));
+        *c->h_bad = 0;
+        PSA_TRY(ensure_tails(c, 1));
+        std::memset(c->h_tails, 0, sizeof(psa::SearchTail));
+        for (auto& s : c->slot) PSA_TRY(init_slot(s));
         {
             // class planes of every Seq1 symbol a over the Seq2 symbols b (group tables only):
             // word a: bit b = class(a, b) in {'*', '.'};  word 32+a: class in {':', '.'}
@@ -855,21 +912,8 @@ psa_status psa_create(int device, void* stream, psa_context** out)
                     if (sign == PSA_SIGN_STAR || sign == PSA_SIGN_DOT) planes[a] |= 1u << b;
                     if (sign == PSA_SIGN_COLON || sign == PSA_SIGN_DOT) planes[32 + a] |= 1u << b;
                 }
-            PSA_HIP(hipMemcpyAsync(c->d_letter_masks, planes, sizeof planes, hipMemcpyHostToDevice, c->stream));
-            PSA_HIP(hipStreamSynchronize(c->stream));
+            PSA_HIP(hipMemcpyAsync(c->d_symbol_planes, planes, sizeof planes, hipMemcpyHostToDevice, c->stream));
         }
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_tail), sizeof(psa::SearchTail)));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bad), sizeof(int)));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_scal), sizeof(Scalars)));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_cand), sizeof(int) * kCandCap));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_rec), sizeof(psa::CandRec) * kCandCap));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_clsrank), psa::kRow * psa::kRow));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_block_best), sizeof(unsigned long long) * psa::kKeyBlocks));
-        c->block_best_cap = psa::kKeyBlocks;
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_tail), sizeof(psa::SearchTail), hipHostMallocDefault));
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_bad), sizeof(int), hipHostMallocDefault));
-        *c->h_bad = 0;
-        std::memset(c->h_tail, 0, sizeof(psa::SearchTail));
         PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
         for (auto& ev : c->ev) PSA_HIP(hipEventCreate(&ev));
         PSA_HIP(hipStreamSynchronize(c->stream));
@@ -886,30 +930,23 @@ void psa_destroy(psa_context* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
     (void)hipFree(c->d_raw);
     (void)hipFree(c->d_s1);
-    (void)hipFree(c->d_s2rows);
-    (void)hipFree(c->d_s2bytes);
+    (void)hipFree(c->d_masks);
     (void)hipFree(c->d_pair);
     (void)hipFree(c->d_rank);
     (void)hipFree(c->d_sub);
-    (void)hipFree(c->d_delta);
-    (void)hipFree(c->d_letter_masks);
     (void)hipFree(c->d_clsrank);
-    (void)hipFree(c->d_blocks);
-    (void)hipFree(c->d_tail);
+    (void)hipFree(c->d_delta);
+    (void)hipFree(c->d_symbol_planes);
     (void)hipFree(c->d_bad);
-    (void)hipFree(c->d_masks);
-    (void)hipFree(c->d_partial);
-    (void)hipFree(c->d_upper);
-    (void)hipFree(c->d_scal);
-    (void)hipFree(c->d_cand);
-    (void)hipFree(c->d_rec);
-    (void)hipFree(c->d_block_best);
-    if (c->h_tail) (void)hipHostFree(c->h_tail);
+    for (auto& s : c->slot) free_slot(s);
+    if (c->h_tails) (void)hipHostFree(c->h_tails);
     if (c->h_bad) (void)hipHostFree(c->h_bad);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -920,11 +957,9 @@ psa_status psa_set_weights(psa_context* c, const double weights[4], int is_max)
     std::string err;
     psa::Tables t;
     if (!psa::build_tables(weights, is_max, &t, &err)) { set_last_error(err); return PSA_ERR_ARG; }
-    psa_status st = ensure_device(c);
-    if (st != PSA_OK) return st;
+    PSA_TRY(ensure_device(c));
     c->tables = t;
-    st = upload_tables(c);
-    if (st != PSA_OK) return st;
+    PSA_TRY(upload_tables(c));
     c->have_weights = true;
     return PSA_OK;
 }
@@ -932,44 +967,34 @@ psa_status psa_set_weights(psa_context* c, const double weights[4], int is_max)
 psa_status psa_set_seq1_device(psa_context* c, const void* d_seq1, int n)
 {
     if (!c || !d_seq1 || n < 1) { set_last_error("psa_set_seq1: bad arguments"); return PSA_ERR_ARG; }
-    psa_status st = ensure_device(c);
-    if (st != PSA_OK) return st;
+    PSA_TRY(ensure_device(c));
     return encode_seq1(c, d_seq1, n);      // alphabet errors surface at psa_search_wait
 }
 
 psa_status psa_set_seq2_device(psa_context* c, const void* d_seq2, int m)
 {
     if (!c || !d_seq2 || m < 1) { set_last_error("psa_set_seq2: bad arguments"); return PSA_ERR_ARG; }
-    psa_status st = ensure_device(c);
-    if (st != PSA_OK) return st;
-    return encode_seq2(c, d_seq2, m);
+    PSA_TRY(ensure_device(c));
+    return encode_seq2(c, c->slot[0], d_seq2, m, c->stream);
 }
 
 psa_status psa_set_seq1(psa_context* c, const char* seq1, int n)
 {
     if (!c || !seq1 || n < 1) { set_last_error("psa_set_seq1: bad arguments"); return PSA_ERR_ARG; }
-    psa_status st = ensure_device(c);
-    if (st != PSA_OK) return st;
-    st = stage_host(c, seq1, n);
-    if (st != PSA_OK) return st;
-    st = encode_seq1(c, c->d_raw, n);
-    if (st != PSA_OK) return st;
-    st = check_bad_now(c);
-    if (st != PSA_OK) return st;
+    PSA_TRY(ensure_device(c));
+    PSA_TRY(stage_host(c, seq1, (size_t)n));
+    PSA_TRY(encode_seq1(c, c->d_raw, n));
+    PSA_TRY(check_bad_now(c));
     return report_bad(c);
 }
 
 psa_status psa_set_seq2(psa_context* c, const char* seq2, int m)
 {
     if (!c || !seq2 || m < 1) { set_last_error("psa_set_seq2: bad arguments"); return PSA_ERR_ARG; }
-    psa_status st = ensure_device(c);
-    if (st != PSA_OK) return st;
-    st = stage_host(c, seq2, m);
-    if (st != PSA_OK) return st;
-    st = encode_seq2(c, c->d_raw, m);
-    if (st != PSA_OK) return st;
-    st = check_bad_now(c);
-    if (st != PSA_OK) return st;
+    PSA_TRY(ensure_device(c));
+    PSA_TRY(stage_host(c, seq2, (size_t)m));
+    PSA_TRY(encode_seq2(c, c->slot[0], c->d_raw, m, c->stream));
+    PSA_TRY(check_bad_now(c));
     return report_bad(c);
 }
 
@@ -982,18 +1007,22 @@ psa_status psa_set_engine(psa_context* c, psa_engine engine)
 
 psa_status psa_search_async(psa_context* c, int first, int last)
 {
-    psa_status st = check_ready(c, first, last);
-    if (st != PSA_OK) return st;
-    st = ensure_device(c);
-    if (st != PSA_OK) return st;
+    if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
+    SearchSlot& s = c->slot[0];
+    PSA_TRY(check_ready(c, s.m, first, last));
+    PSA_TRY(ensure_device(c));
     c->timing_valid = false;
     if (c->profiling) PSA_HIP(hipEventRecord(c->ev[0], c->stream));
-    c->pending_filter = use_filter(c, first, last);
+    c->pending_filter = use_filter(c, first, last, s.m);
     c->pending_first = first;
     c->pending_last = last;
-    st = c->pending_filter ? launch_filter(c, first, last) : launch_sequential(c, first, last, nullptr, nullptr);
-    if (st != PSA_OK) return st;
-    PSA_HIP(hipMemcpyAsync(c->h_tail, c->d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
+    if (c->pending_filter) {
+        PSA_TRY(launch_filter_front(c, s, first, last, c->stream, c->profiling));
+        PSA_TRY(launch_filter_back(c, s, (long long)(last - first) * s.m, c->stream));
+    } else {
+        PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream));
+    }
+    PSA_HIP(hipMemcpyAsync(&c->h_tails[0], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
     if (c->profiling) {
         PSA_HIP(hipEventRecord(c->ev[1], c->stream));
         c->timing_valid = true;
@@ -1008,20 +1037,18 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
     if (!c->pending) { set_last_error("psa_search_wait: no search in flight"); return PSA_ERR_STATE; }
     PSA_HIP(hipStreamSynchronize(c->stream));
     c->pending = false;
-    *c->h_bad = c->h_tail->bad;
-    psa_status st = report_bad(c);            // device-resident sequences are validated here
-    if (st != PSA_OK) return st;
-    if (c->pending_filter && c->h_tail->overflow) {
+    *c->h_bad = c->h_tails[0].bad;
+    PSA_TRY(report_bad(c));                   // device-resident sequences are validated here
+    if (c->pending_filter && c->h_tails[0].overflow) {
         // more near-tied offsets than the candidate list holds (e.g. a homopolymer):
         // score every offset in reference order instead
         c->fallbacks += 1;
-        st = launch_sequential(c, c->pending_first, c->pending_last, nullptr, nullptr);
-        if (st != PSA_OK) return st;
-        PSA_HIP(hipMemcpyAsync(c->h_tail, c->d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
+        PSA_TRY(launch_sequential(c, c->slot[0], c->pending_first, c->pending_last, nullptr, nullptr, c->stream));
+        PSA_HIP(hipMemcpyAsync(&c->h_tails[0], c->slot[0].d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
         PSA_HIP(hipStreamSynchronize(c->stream));
         c->timing_valid = false;
     }
-    *out = c->h_tail->result;
+    *out = c->h_tails[0].result;
     if (c->profiling && c->timing_valid) {
         float a = 0.f, b = 0.f;
         PSA_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
@@ -1035,31 +1062,98 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
 
 psa_status psa_search(psa_context* c, int first, int last, psa_result* out)
 {
-    psa_status st = psa_search_async(c, first, last);
-    if (st != PSA_OK) return st;
+    PSA_TRY(psa_search_async(c, first, last));
     return psa_search_wait(c, out);
+}
+
+// nq queries of m characters each, `stride` bytes apart in one device buffer, against the
+// context's Seq1 and weights; results[q] in host memory.  Query q+1's count kernel runs on
+// the main stream while query q's re-score and read-back run on the context's second stream.
+psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq, int m, size_t stride,
+                                   int first, int last, psa_result* results)
+{
+    if (!c || !d_queries || !results || nq < 1 || stride < (size_t)m) {
+        set_last_error("psa_search_batch: bad arguments");
+        return PSA_ERR_ARG;
+    }
+    PSA_TRY(check_ready(c, m, first, last));
+    PSA_TRY(ensure_device(c));
+    PSA_TRY(ensure_tails(c, nq));
+    const unsigned char* base = static_cast<const unsigned char*>(d_queries);
+    const bool filter = use_filter(c, first, last, m);
+    const long long pairs = (long long)(last - first) * m;
+    // the aux stream must see everything already enqueued on the main stream (Seq1 planes, tables)
+    hipEvent_t& gate = c->slot[0].front_done;
+    PSA_HIP(hipEventRecord(gate, c->stream));
+    PSA_HIP(hipStreamWaitEvent(c->aux, gate, 0));
+    for (int q = 0; q < nq; ++q) {
+        SearchSlot& s = c->slot[q % kSlots];
+        if (q >= kSlots) PSA_HIP(hipStreamWaitEvent(c->stream, s.back_done, 0));   // slot free again
+        PSA_TRY(encode_seq2(c, s, base + (size_t)q * stride, m, c->stream));
+        if (filter) {
+            PSA_TRY(launch_filter_front(c, s, first, last, c->stream, false));
+            PSA_HIP(hipEventRecord(s.front_done, c->stream));
+            PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
+            PSA_TRY(launch_filter_back(c, s, pairs, c->aux));
+        } else {
+            PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream));
+            PSA_HIP(hipEventRecord(s.front_done, c->stream));
+            PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
+        }
+        PSA_HIP(hipMemcpyAsync(&c->h_tails[q], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->aux));
+        PSA_HIP(hipEventRecord(s.back_done, c->aux));
+    }
+    PSA_HIP(hipStreamSynchronize(c->aux));
+    PSA_HIP(hipStreamSynchronize(c->stream));
+    int bad = 0;
+    for (int q = 0; q < nq; ++q) bad |= c->h_tails[q].bad;
+    *c->h_bad = bad;
+    PSA_TRY(report_bad(c));
+    for (int q = 0; q < nq; ++q) {
+        if (filter && c->h_tails[q].overflow) {
+            SearchSlot& s = c->slot[0];
+            c->fallbacks += 1;
+            PSA_TRY(encode_seq2(c, s, base + (size_t)q * stride, m, c->stream));
+            PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream));
+            PSA_HIP(hipMemcpyAsync(&c->h_tails[q], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
+            PSA_HIP(hipStreamSynchronize(c->stream));
+        }
+        results[q] = c->h_tails[q].result;
+        results[q].shard = q;
+    }
+    c->slot[0].m = -1;      // the single-search Seq2 was overwritten by the batch
+    return PSA_OK;
+}
+
+psa_status psa_search_batch(psa_context* c, const char* queries, int nq, int m, size_t stride,
+                            int first, int last, psa_result* results)
+{
+    if (!c || !queries || nq < 1 || stride < (size_t)m) { set_last_error("psa_search_batch: bad arguments"); return PSA_ERR_ARG; }
+    PSA_TRY(ensure_device(c));
+    PSA_TRY(stage_host(c, queries, (size_t)(nq - 1) * stride + (size_t)m));
+    PSA_HIP(hipStreamSynchronize(c->stream));
+    return psa_search_batch_device(c, c->d_raw, nq, m, stride, first, last, results);
 }
 
 psa_status psa_scores(psa_context* c, int first, int last, double* scores, int32_t* char_offsets, int32_t* chs)
 {
-    psa_status st = check_ready(c, first, last);
-    if (st != PSA_OK) return st;
-    st = ensure_device(c);
-    if (st != PSA_OK) return st;
+    if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
+    SearchSlot& s = c->slot[0];
+    PSA_TRY(check_ready(c, s.m, first, last));
+    PSA_TRY(ensure_device(c));
     const int span = last - first;
     double* d_score = nullptr;
     unsigned char* d_prank = nullptr;
     int* d_ci = nullptr;
     int* d_ch = nullptr;
-    st = [&]() -> psa_status {
+    psa_status st = [&]() -> psa_status {
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_score), sizeof(double) * (size_t)span));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_prank), (size_t)span));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_ci), sizeof(int) * (size_t)span));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_ch), sizeof(int) * (size_t)span));
-        psa_status s2 = launch_sequential(c, first, last, d_score, d_prank);
-        if (s2 != PSA_OK) return s2;
+        PSA_TRY(launch_sequential(c, s, first, last, d_score, d_prank, c->stream));
         hipLaunchKernelGGL(psa::psa_first_index_kernel, dim3((span + 255) / 256), dim3(256), 0, c->stream,
-                           c->d_s1, c->d_s2rows, c->d_rank, c->d_sub, d_prank, first, last, c->m, d_ci, d_ch);
+                           c->d_s1, s.d_s2rows, c->d_rank, c->d_sub, d_prank, first, last, s.m, d_ci, d_ch);
         PSA_HIP(hipGetLastError());
         if (scores) PSA_HIP(hipMemcpyAsync(scores, d_score, sizeof(double) * (size_t)span, hipMemcpyDeviceToHost, c->stream));
         if (char_offsets) PSA_HIP(hipMemcpyAsync(char_offsets, d_ci, sizeof(int) * (size_t)span, hipMemcpyDeviceToHost, c->stream));
@@ -1080,30 +1174,33 @@ psa_status psa_scores(psa_context* c, int first, int last, double* scores, int32
 psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_star, uint32_t* n_colon,
                             uint32_t* n_dot)
 {
-    psa_status st = check_ready(c, first, last);
-    if (st != PSA_OK) return st;
-    st = ensure_device(c);
-    if (st != PSA_OK) return st;
+    if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
+    SearchSlot& s = c->slot[0];
+    PSA_TRY(check_ready(c, s.m, first, last));
+    PSA_TRY(ensure_device(c));
     const int span = last - first;
     const int base = first & ~31;
     const int lead = first - base;
     FilterPlan p;
-    if (!plan_filter(first, last, c->m, &p)) { set_last_error("internal: no filter plan"); return PSA_ERR_ARG; }
+    if (!plan_filter(first, last, s.m, &p)) { set_last_error("internal: no filter plan"); return PSA_ERR_ARG; }
     const int span_pad = p.ntiles * psa::kTile;
     const size_t need = (size_t)p.nchunks * span_pad;
-    if (need > c->partial_cap) {
-        st = dev_alloc(&c->d_partial, need);
-        if (st != PSA_OK) { c->partial_cap = 0; return st; }
-        c->partial_cap = need;
+    if (need > s.partial_cap) {
+        s.partial_cap = 0;
+        PSA_TRY(dev_alloc(&s.d_partial, need));
+        s.partial_cap = need;
     }
-    st = launch_count(c, p, base, span_pad, first, 0);
-    if (st != PSA_OK) return st;
+    if (psa::kKeyBlocks > s.block_best_cap) {
+        s.block_best_cap = 0;
+        PSA_TRY(dev_alloc(&s.d_block_best, (size_t)std::max(p.ntiles, psa::kKeyBlocks)));
+        s.block_best_cap = std::max(p.ntiles, psa::kKeyBlocks);
+    }
+    PSA_TRY(launch_count(c, s, p, base, span_pad, first, 0, c->stream));
     std::vector<unsigned long long> host(need);
-    PSA_HIP(hipMemcpyAsync(host.data(), c->d_partial, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    PSA_HIP(hipMemcpyAsync(host.data(), s.d_partial, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     PSA_HIP(hipStreamSynchronize(c->stream));
-    st = report_bad(c);
-    if (st != PSA_OK) return st;
+    PSA_TRY(report_bad(c));
     for (int o = 0; o < span; ++o) {
         unsigned long long sum = 0;
         for (int k = 0; k < p.nchunks; ++k) sum += host[(size_t)k * span_pad + lead + o];
@@ -1124,27 +1221,24 @@ psa_status psa_debug_rescore(psa_context* c, const int32_t* offsets, int count, 
         set_last_error("psa_debug_rescore: bad arguments (1 <= count <= 2048)");
         return PSA_ERR_ARG;
     }
-    psa_status st = check_ready(c, 0, 1);
-    if (st != PSA_OK) return st;
-    st = ensure_device(c);
-    if (st != PSA_OK) return st;
-    const int total = c->n - c->m + 1;
+    SearchSlot& s = c->slot[0];
+    PSA_TRY(check_ready(c, s.m, 0, 1));
+    PSA_TRY(ensure_device(c));
+    const int total = c->n - s.m + 1;
     for (int k = 0; k < count; ++k)
         if (offsets[k] < 0 || offsets[k] >= total) { set_last_error("psa_debug_rescore: offset out of range"); return PSA_ERR_ARG; }
     Scalars sc;
     sc.cand_count = count;
     sc.done = 0;
     sc.spare = 0;
-    PSA_HIP(hipMemcpyAsync(c->d_scal, &sc, sizeof sc, hipMemcpyHostToDevice, c->stream));
-    PSA_HIP(hipMemcpyAsync(c->d_cand, offsets, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    st = launch_rescore(c, 0);
-    if (st != PSA_OK) return st;
+    PSA_HIP(hipMemcpyAsync(s.d_scal, &sc, sizeof sc, hipMemcpyHostToDevice, c->stream));
+    PSA_HIP(hipMemcpyAsync(s.d_cand, offsets, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, c->stream));
+    PSA_TRY(launch_filter_back(c, s, 0, c->stream));
     std::vector<psa::CandRec> host((size_t)count);
-    PSA_HIP(hipMemcpyAsync(host.data(), c->d_rec, sizeof(psa::CandRec) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
+    PSA_HIP(hipMemcpyAsync(host.data(), s.d_rec, sizeof(psa::CandRec) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     PSA_HIP(hipStreamSynchronize(c->stream));
-    st = report_bad(c);
-    if (st != PSA_OK) return st;
+    PSA_TRY(report_bad(c));
     for (int k = 0; k < count; ++k) scores[k] = host[(size_t)k].score;
     return PSA_OK;
 }

@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "psa_create", "psa_destroy", "psa_set_weights",
     "psa_set_seq1", "psa_set_seq2", "psa_set_seq1_device", "psa_set_seq2_device",
     "psa_set_engine", "psa_search", "psa_search_async", "psa_search_wait", "psa_scores",
+    "psa_search_batch", "psa_search_batch_device",
     "psa_debug_counts", "psa_fallback_count", "psa_debug_rescore",
     "psa_fold", "psa_shard_range", "psa_build_tables",
     "psa_set_profiling", "psa_last_timing", "psa_profile_totals",
@@ -80,6 +81,8 @@ def _load() -> C.CDLL:
     lib.psa_search_async.argtypes = [vp, i, i]
     lib.psa_search_wait.argtypes = [vp, C.POINTER(Result)]
     lib.psa_scores.argtypes = [vp, i, i, vp, vp, vp]
+    lib.psa_search_batch.argtypes = [vp, C.c_char_p, i, i, C.c_size_t, i, i, C.POINTER(Result)]
+    lib.psa_search_batch_device.argtypes = [vp, vp, i, i, C.c_size_t, i, i, C.POINTER(Result)]
     lib.psa_debug_counts.argtypes = [vp, i, i, vp, vp, vp]
     lib.psa_fallback_count.argtypes = [vp]
     lib.psa_debug_rescore.argtypes = [vp, vp, i, vp]
@@ -225,6 +228,28 @@ class Context:
         out = Result()
         _check(lib.psa_search_wait(self._h, C.byref(out)))
         return out
+
+    def search_batch(self, queries: Sequence[bytes], first: Optional[int] = None, last: Optional[int] = None):
+        """Equal-length host queries -> list of Result (psa_search_batch)."""
+        m = len(queries[0])
+        if any(len(q) != m for q in queries):
+            raise ValueError("all queries of a batch must have the same length")
+        first = 0 if first is None else first
+        last = self.n - m + 1 if last is None else last
+        out = (Result * len(queries))()
+        _check(lib.psa_search_batch(self._h, b"".join(queries), len(queries), m, m, first, last, out))
+        self.m = None
+        return list(out)
+
+    def search_batch_device(self, ptr: int, nq: int, m: int, stride: int,
+                            first: Optional[int] = None, last: Optional[int] = None):
+        """Queries already in HBM, `stride` bytes apart (psa_search_batch_device)."""
+        first = 0 if first is None else first
+        last = self.n - m + 1 if last is None else last
+        out = (Result * nq)()
+        _check(lib.psa_search_batch_device(self._h, C.c_void_p(ptr), nq, m, stride, first, last, out))
+        self.m = None
+        return list(out)
 
     def scores(self, first: Optional[int] = None, last: Optional[int] = None):
         first = 0 if first is None else first

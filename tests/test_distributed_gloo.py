@@ -58,3 +58,43 @@ def test_shard_exchange_fold(oracle, psa, reference_records, world, rec):
         lo, hi = psa.shard_range(total, world, got[4])
         assert lo <= got[1] < hi            # the winning shard is the one that owns the offset
         assert got[5] == total * len(s2)
+
+
+def _batch_worker(rank, world, port, case, out):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import psa_amd as psa
+    import bench
+    from oracle import oracle
+    w, s1, queries, is_max = case
+    lo, hi = bench.query_block(len(queries), world, rank)
+    mine = []
+    for q in range(lo, hi):
+        score, off, ci, ch = oracle.search(s1, queries[q], w, is_max, threads=1)
+        rec = psa.Result()
+        rec.score, rec.offset, rec.char_offset, rec.ch, rec.shard, rec.pairs = score, off, ci, ord(ch), q, 1
+        mine.append(rec)
+    got = bench.gather_records(psa, dist, torch, mine, lo, len(queries), torch.device("cpu"))
+    out[rank] = [(g.score, g.offset, g.char_offset, chr(g.ch), g.shard) for g in got]
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,nq", [(2, 5), (3, 7)])
+def test_query_sharded_batch_gather(oracle, psa, world, nq):
+    """bench.py's default N>1 path: queries dealt to ranks in contiguous blocks, one all-reduce
+    of the one-hot record buffer; every rank ends with every query's record."""
+    s1 = psa.generate_sequence(301, 3000)
+    queries = [psa.generate_sequence(400 + q, 64) for q in range(nq)]
+    w = [1.5, 2.6, 0.3, 0.2]
+    want = [oracle.search(s1, q, w, True, threads=2) + (k,) for k, q in enumerate(queries)]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_batch_worker, args=(world, _free_port(), (w, s1, queries, True), out), nprocs=world, join=True)
+    for rank in range(world):
+        assert out[rank] == want
+    blocks = [__import__("bench").query_block(nq, world, r) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == nq and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))

@@ -393,3 +393,57 @@ def test_rescore_walk_is_bit_exact(psa, oracle, w):
                 got = np.concatenate([c.debug_rescore(offs[k:k + 2048]) for k in range(0, total, 2048)])
                 want, _, _ = oracle.scores(s1, s2, w, is_max)
                 assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (w, is_max, len(s2))
+
+
+def test_batch_matches_oracle_and_single_searches(psa, oracle):
+    """psa_search_batch: per-query results == oracle (small) and == psa_search (1M x 10k), both engines,
+    including a query whose candidate list overflows (falls back inside the batch)."""
+    s1 = psa.generate_sequence(81, 40000)
+    queries = [psa.generate_sequence(900 + q, 300) for q in range(7)]
+    queries[3] = s1[1234:1534]                        # an exact copy: unique best in max mode
+    for engine in (psa.ENGINE_FILTER, psa.ENGINE_SEQUENTIAL):
+        with psa.Context(0) as c:
+            c.set_engine(engine)
+            for is_max in (True, False):
+                c.set_weights(W_README, is_max)
+                c.set_seq1(s1)
+                got = c.search_batch(queries)
+                for q, res in zip(queries, got):
+                    assert_same(res, oracle.search(s1, q, W_README, is_max, threads=8))
+                sub = c.search_batch(queries[:3], 100, 20000)
+                for q, res in zip(queries, sub):
+                    assert_same(res, oracle.search(s1, q, W_README, is_max, 100, 20000, threads=8))
+    # tie-heavy query inside a batch -> per-query fallback
+    with psa.Context(0) as c:
+        c.set_engine(psa.ENGINE_FILTER)
+        c.set_weights([1, 1, 1, 1], True)
+        s1 = b"A" * 9000                       # every offset ties for the homopolymer queries
+        qs = [b"A" * 200, psa.generate_sequence(6, 200), b"A" * 200]
+        c.set_seq1(s1)
+        got = c.search_batch(qs)
+        for q, res in zip(qs, got):
+            assert_same(res, oracle.search(s1, q, [1, 1, 1, 1], True, threads=8))
+        assert c.fallback_count() >= 2
+
+
+def test_batch_full_size_device_queries(psa):
+    """Four 1M x 10k queries in HBM through the pipelined batch path == four single searches."""
+    import torch
+    n, m, nq = 1_000_000, 10_000, 4
+    s1 = psa.generate_sequence_np(1002, n)
+    qs = np.stack([psa.generate_sequence_np(2002 + q, m) for q in range(nq)])
+    t1 = torch.from_numpy(s1).cuda()
+    tq = torch.from_numpy(qs).cuda()
+    with psa.Context(0) as c:
+        c.set_weights(W_README, True)
+        c.set_seq1_device(t1.data_ptr(), n)
+        batch = c.search_batch_device(tq.data_ptr(), nq, m, m)
+        for q in range(nq):
+            c.set_seq2_device(tq[q].data_ptr(), m)
+            one = c.search()
+            b = batch[q]
+            assert (b.score, b.offset, b.char_offset, b.ch, b.pairs) == (one.score, one.offset, one.char_offset, one.ch, one.pairs)
+            assert b.shard == q
+        gold = {c_["name"]: c_ for c_ in json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))["cases"]}["c3_max"]
+        assert (batch[0].offset, batch[0].char_offset, chr(batch[0].ch), "%.17g" % batch[0].score) == \
+               (gold["offset"], gold["char_offset"], gold["ch"], gold["score"])
