@@ -310,10 +310,10 @@ constexpr int kSeq1Slack = 49152;     // code-27 tail behind Seq1: tile + chunk 
 constexpr int kSeq2Slack = 32768 + 64;
 constexpr int kSlots = 2;             // searches in flight inside a batch
 
-struct Scalars {                      // small device-side state of one filter search
+struct Scalars {                      // small device-side state of one filter search (zero between searches)
+    unsigned long long global_best;   // ordered-u64 of the best pessimistic bound seen so far
     int cand_count;
     int done;                         // candidate workgroups that have finished re-scoring
-    int spare;
 };
 
 struct FilterPlan {
@@ -340,14 +340,18 @@ psa_status dev_alloc(T** ptr, size_t count)
 // overlaps the count kernel of query q+1.
 struct SearchSlot {
     int m = -1, m_cap = 0;
-    unsigned int*       d_s2rows = nullptr;    // Seq2 codes as u32 (sequential engine: scalar loads)
-    unsigned char*      d_s2bytes = nullptr;   // Seq2 codes as bytes (filter engine)
+    unsigned int*       d_s2rows = nullptr;    // owned: Seq2 codes as u32 (sequential engine: scalar loads)
+    unsigned char*      d_s2bytes = nullptr;   // owned: Seq2 codes as bytes (filter engine)
+    const unsigned int*  s2rows = nullptr;     // the codes this slot searches: its own buffers, or one
+    const unsigned char* s2bytes = nullptr;    // query of the batch buffer
+    bool                inline_select = false; // the count kernel picked the candidates itself
     psa::BlockRec*      d_blocks = nullptr;    int blocks_cap = 0;      // sequential engine
     unsigned long long* d_partial = nullptr;   size_t partial_cap = 0;
     double*             d_upper = nullptr;     size_t upper_cap = 0;
     unsigned long long* d_block_best = nullptr; int block_best_cap = 0;
     Scalars*            d_scal = nullptr;
     int*                d_cand = nullptr;
+    double*             d_cand_upper = nullptr;
     psa::CandRec*       d_rec = nullptr;
     psa::SearchTail*    d_tail = nullptr;
     hipEvent_t          front_done = nullptr;  // count + select enqueued
@@ -379,6 +383,8 @@ struct psa_context {
     int*           d_bad = nullptr;
     int*           h_bad = nullptr;       // pinned
     psa::SearchTail* h_tails = nullptr;   int tails_cap = 0;     // pinned, one per query of a batch (>= 1)
+    unsigned int*  d_batch_rows = nullptr;   // codes of all queries of a batch
+    unsigned char* d_batch_bytes = nullptr;  size_t batch_cap = 0;
 
     SearchSlot  slot[kSlots];
 
@@ -479,6 +485,8 @@ psa_status encode_seq2(psa_context* c, SearchSlot& s, const void* d_raw, int m, 
                        static_cast<const unsigned char*>(d_raw), m, s.d_s2rows, s.d_s2bytes, s.m_cap, c->d_bad);
     PSA_HIP(hipGetLastError());
     s.m = m;
+    s.s2rows = s.d_s2rows;
+    s.s2bytes = s.d_s2bytes;
     return PSA_OK;
 }
 
@@ -528,7 +536,7 @@ psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last,
     }
     psa::SeqArgs a;
     a.s1 = c->d_s1;
-    a.s2rows = s.d_s2rows;
+    a.s2rows = s.s2rows;
     a.pair = c->d_pair;
     a.rank = c->d_rank;
     a.delta_of_rank = c->d_delta;
@@ -564,7 +572,7 @@ psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last,
     f.block_in = s.d_blocks;
     f.nblocks = nblocks;
     f.s1 = c->d_s1;
-    f.s2rows = s.d_s2rows;
+    f.s2rows = s.s2rows;
     f.rank = c->d_rank;
     f.sub = c->d_sub;
     f.out = s.d_tail;
@@ -663,11 +671,11 @@ psa::BoundParams bound_params(const psa_context* c, int m)
 // first/span describe the searched range when the kernel should also produce the score
 // bounds (single-chunk plans); span = 0 writes raw partial counts instead.
 psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int base, int span_pad, int first,
-                        int span, hipStream_t stream)
+                        int span, bool inline_select, hipStream_t stream)
 {
     psa::CountArgs a;
     a.masks = c->d_masks;
-    a.s2 = s.d_s2bytes;
+    a.s2 = s.s2bytes;
     a.partial = s.d_partial;
     a.nslots = c->nslots;
     a.base = base;
@@ -675,21 +683,33 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.chunk_chars = p.chunk_chars;
     a.wave_chars = p.wave_chars;
     a.lds_slots = p.lds_slots;
-    a.zero = &s.d_scal->cand_count;      // the search scalars: cleared here for the kernels behind this one
-    a.upper = span > 0 ? s.d_upper : nullptr;
-    a.block_best = s.d_block_best;
+    a.inline_select = inline_select ? 1 : 0;
+    a.global_best = &s.d_scal->global_best;
+    a.cand = s.d_cand;
+    a.cand_upper = s.d_cand_upper;
+    a.cand_count = &s.d_scal->cand_count;
+    a.cap = kCandCap;
+    a.first = first;
     a.lead = first - base;
     a.span = span;
     a.bounds = bound_params(c, s.m);
     const dim3 grid(p.ntiles, p.nchunks);
+    // dynamic LDS above 64 KB has to be granted per kernel; remember the largest grant
+    static int granted16 = 0, granted8 = 0;
     if (p.waves == 16) {
-        PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_bytes));
+        if (p.lds_bytes > granted16) {
+            PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+            granted16 = kLdsLimit;
+        }
         hipLaunchKernelGGL(psa::psa_count_kernel<16>, grid, dim3(16 * 64), p.lds_bytes, stream, a);
         c->last_kernel = "psa_count_kernel<16>";
     } else {
-        PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<8>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, p.lds_bytes));
+        if (p.lds_bytes > granted8) {
+            PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<8>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+            granted8 = kLdsLimit;
+        }
         hipLaunchKernelGGL(psa::psa_count_kernel<8>, grid, dim3(8 * 64), p.lds_bytes, stream, a);
         c->last_kernel = "psa_count_kernel<8>";
     }
@@ -708,46 +728,45 @@ psa_status launch_filter_front(psa_context* c, SearchSlot& s, int first, int las
         return PSA_ERR_ARG;
     }
     const int span_pad = p.ntiles * psa::kTile;
-    const bool inline_keys = p.nchunks == 1;
-    if (!inline_keys) {
-        const size_t need_partial = (size_t)p.nchunks * span_pad;
-        if (need_partial > s.partial_cap) {
-            s.partial_cap = 0;
-            PSA_TRY(dev_alloc(&s.d_partial, need_partial));
-            s.partial_cap = need_partial;
-        }
+    s.inline_select = p.nchunks == 1;
+    if (profile) PSA_HIP(hipEventRecord(c->ev[2], stream));
+    if (s.inline_select) {
+        PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, true, stream));
+        if (profile) PSA_HIP(hipEventRecord(c->ev[3], stream));
+        return PSA_OK;
+    }
+    // several char chunks: partial counts -> keys kernel -> select kernel
+    const size_t need_partial = (size_t)p.nchunks * span_pad;
+    if (need_partial > s.partial_cap) {
+        s.partial_cap = 0;
+        PSA_TRY(dev_alloc(&s.d_partial, need_partial));
+        s.partial_cap = need_partial;
     }
     if ((size_t)span > s.upper_cap) {
         s.upper_cap = 0;
         PSA_TRY(dev_alloc(&s.d_upper, (size_t)span));
         s.upper_cap = (size_t)span;
     }
-    const int need_best = std::max(p.ntiles, psa::kKeyBlocks);
-    if (need_best > s.block_best_cap) {
+    if (psa::kKeyBlocks > s.block_best_cap) {
         s.block_best_cap = 0;
-        PSA_TRY(dev_alloc(&s.d_block_best, (size_t)need_best));
-        s.block_best_cap = need_best;
+        PSA_TRY(dev_alloc(&s.d_block_best, (size_t)psa::kKeyBlocks));
+        s.block_best_cap = psa::kKeyBlocks;
     }
-
-    if (profile) PSA_HIP(hipEventRecord(c->ev[2], stream));
-    PSA_TRY(launch_count(c, s, p, base, span_pad, first, inline_keys ? span : 0, stream));
+    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, false, stream));
     if (profile) PSA_HIP(hipEventRecord(c->ev[3], stream));
 
-    int nbest = p.ntiles;
-    if (!inline_keys) {
-        psa::KeyArgs k;
-        k.partial = s.d_partial;
-        k.upper = s.d_upper;
-        k.block_best = s.d_block_best;
-        k.bounds = bound_params(c, s.m);
-        k.nchunks = p.nchunks;
-        k.span_pad = span_pad;
-        k.span = span;
-        k.lead = first - base;
-        nbest = std::min(psa::kKeyBlocks, (span + 255) / 256);
-        hipLaunchKernelGGL(psa::psa_keys_kernel, dim3(nbest), dim3(256), 0, stream, k);
-        PSA_HIP(hipGetLastError());
-    }
+    psa::KeyArgs k;
+    k.partial = s.d_partial;
+    k.upper = s.d_upper;
+    k.block_best = s.d_block_best;
+    k.bounds = bound_params(c, s.m);
+    k.nchunks = p.nchunks;
+    k.span_pad = span_pad;
+    k.span = span;
+    k.lead = first - base;
+    const int nbest = std::min(psa::kKeyBlocks, (span + 255) / 256);
+    hipLaunchKernelGGL(psa::psa_keys_kernel, dim3(nbest), dim3(256), 0, stream, k);
+    PSA_HIP(hipGetLastError());
 
     psa::SelectArgs sel;
     sel.upper = s.d_upper;
@@ -758,8 +777,7 @@ psa_status launch_filter_front(psa_context* c, SearchSlot& s, int first, int las
     sel.span = span;
     sel.first = first;
     sel.cap = kCandCap;
-    hipLaunchKernelGGL(psa::psa_select_kernel, dim3(std::min(psa::kKeyBlocks, (span + 255) / 256)), dim3(256), 0,
-                       stream, sel);
+    hipLaunchKernelGGL(psa::psa_select_kernel, dim3(nbest), dim3(256), 0, stream, sel);
     PSA_HIP(hipGetLastError());
     return PSA_OK;
 }
@@ -770,11 +788,13 @@ psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hi
     const psa::Tables& t = c->tables;
     psa::RescoreArgs r;
     r.s1 = c->d_s1;
-    r.s2 = s.d_s2bytes;
+    r.s2 = s.s2bytes;
     r.clsrank = c->d_clsrank;
     r.sub = c->d_sub;
     r.delta_of_rank = c->d_delta;
     r.cand = s.d_cand;
+    r.cand_upper = s.inline_select ? s.d_cand_upper : nullptr;
+    r.global_best = &s.d_scal->global_best;
     r.cand_count = &s.d_scal->cand_count;
     r.rec = s.d_rec;
     r.done = &s.d_scal->done;
@@ -840,7 +860,9 @@ psa_status check_ready(psa_context* c, int m, int first, int last)
 psa_status init_slot(SearchSlot& s)
 {
     PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_scal), sizeof(Scalars)));
+    PSA_HIP(hipMemset(s.d_scal, 0, sizeof(Scalars)));
     PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_cand), sizeof(int) * kCandCap));
+    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_cand_upper), sizeof(double) * kCandCap));
     PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_rec), sizeof(psa::CandRec) * kCandCap));
     PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_tail), sizeof(psa::SearchTail)));
     PSA_HIP(hipEventCreateWithFlags(&s.front_done, hipEventDisableTiming));
@@ -858,6 +880,7 @@ void free_slot(SearchSlot& s)
     (void)hipFree(s.d_block_best);
     (void)hipFree(s.d_scal);
     (void)hipFree(s.d_cand);
+    (void)hipFree(s.d_cand_upper);
     (void)hipFree(s.d_rec);
     (void)hipFree(s.d_tail);
     if (s.front_done) (void)hipEventDestroy(s.front_done);
@@ -942,6 +965,8 @@ void psa_destroy(psa_context* c)
     (void)hipFree(c->d_symbol_planes);
     (void)hipFree(c->d_bad);
     for (auto& s : c->slot) free_slot(s);
+    (void)hipFree(c->d_batch_rows);
+    (void)hipFree(c->d_batch_bytes);
     if (c->h_tails) (void)hipHostFree(c->h_tails);
     if (c->h_bad) (void)hipHostFree(c->h_bad);
     for (auto& ev : c->ev)
@@ -1017,6 +1042,7 @@ psa_status psa_search_async(psa_context* c, int first, int last)
     c->pending_first = first;
     c->pending_last = last;
     if (c->pending_filter) {
+        PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));   // normally already clean (self-resetting)
         PSA_TRY(launch_filter_front(c, s, first, last, c->stream, c->profiling));
         PSA_TRY(launch_filter_back(c, s, (long long)(last - first) * s.m, c->stream));
     } else {
@@ -1082,14 +1108,28 @@ psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq
     const unsigned char* base = static_cast<const unsigned char*>(d_queries);
     const bool filter = use_filter(c, first, last, m);
     const long long pairs = (long long)(last - first) * m;
-    // the aux stream must see everything already enqueued on the main stream (Seq1 planes, tables)
+    // all queries encoded by one launch: [nq][ostride] codes as u32 rows and as bytes
+    const int ostride = (m + kSeq2Slack + 63) & ~63;
+    if ((size_t)nq * ostride > c->batch_cap) {
+        c->batch_cap = 0;
+        PSA_TRY(dev_alloc(&c->d_batch_rows, (size_t)nq * ostride));
+        PSA_TRY(dev_alloc(&c->d_batch_bytes, (size_t)nq * ostride));
+        c->batch_cap = (size_t)nq * ostride;
+    }
+    hipLaunchKernelGGL(psa::psa_encode_batch_kernel, dim3((ostride + 255) / 256, nq), dim3(256), 0, c->stream,
+                       base, nq, m, stride, c->d_batch_rows, c->d_batch_bytes, ostride, c->d_bad);
+    PSA_HIP(hipGetLastError());
+    for (auto& s : c->slot) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
+    // the aux stream must see everything already enqueued on the main stream (Seq1 planes, tables, codes)
     hipEvent_t& gate = c->slot[0].front_done;
     PSA_HIP(hipEventRecord(gate, c->stream));
     PSA_HIP(hipStreamWaitEvent(c->aux, gate, 0));
     for (int q = 0; q < nq; ++q) {
         SearchSlot& s = c->slot[q % kSlots];
         if (q >= kSlots) PSA_HIP(hipStreamWaitEvent(c->stream, s.back_done, 0));   // slot free again
-        PSA_TRY(encode_seq2(c, s, base + (size_t)q * stride, m, c->stream));
+        s.m = m;
+        s.s2rows = c->d_batch_rows + (size_t)q * ostride;
+        s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
         if (filter) {
             PSA_TRY(launch_filter_front(c, s, first, last, c->stream, false));
             PSA_HIP(hipEventRecord(s.front_done, c->stream));
@@ -1113,7 +1153,9 @@ psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq
         if (filter && c->h_tails[q].overflow) {
             SearchSlot& s = c->slot[0];
             c->fallbacks += 1;
-            PSA_TRY(encode_seq2(c, s, base + (size_t)q * stride, m, c->stream));
+            s.m = m;
+            s.s2rows = c->d_batch_rows + (size_t)q * ostride;
+            s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
             PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream));
             PSA_HIP(hipMemcpyAsync(&c->h_tails[q], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
             PSA_HIP(hipStreamSynchronize(c->stream));
@@ -1121,7 +1163,7 @@ psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq
         results[q] = c->h_tails[q].result;
         results[q].shard = q;
     }
-    c->slot[0].m = -1;      // the single-search Seq2 was overwritten by the batch
+    for (auto& s : c->slot) s.m = -1;      // the single-search Seq2 is gone
     return PSA_OK;
 }
 
@@ -1153,7 +1195,7 @@ psa_status psa_scores(psa_context* c, int first, int last, double* scores, int32
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_ch), sizeof(int) * (size_t)span));
         PSA_TRY(launch_sequential(c, s, first, last, d_score, d_prank, c->stream));
         hipLaunchKernelGGL(psa::psa_first_index_kernel, dim3((span + 255) / 256), dim3(256), 0, c->stream,
-                           c->d_s1, s.d_s2rows, c->d_rank, c->d_sub, d_prank, first, last, s.m, d_ci, d_ch);
+                           c->d_s1, s.s2rows, c->d_rank, c->d_sub, d_prank, first, last, s.m, d_ci, d_ch);
         PSA_HIP(hipGetLastError());
         if (scores) PSA_HIP(hipMemcpyAsync(scores, d_score, sizeof(double) * (size_t)span, hipMemcpyDeviceToHost, c->stream));
         if (char_offsets) PSA_HIP(hipMemcpyAsync(char_offsets, d_ci, sizeof(int) * (size_t)span, hipMemcpyDeviceToHost, c->stream));
@@ -1190,12 +1232,7 @@ psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_sta
         PSA_TRY(dev_alloc(&s.d_partial, need));
         s.partial_cap = need;
     }
-    if (psa::kKeyBlocks > s.block_best_cap) {
-        s.block_best_cap = 0;
-        PSA_TRY(dev_alloc(&s.d_block_best, (size_t)std::max(p.ntiles, psa::kKeyBlocks)));
-        s.block_best_cap = std::max(p.ntiles, psa::kKeyBlocks);
-    }
-    PSA_TRY(launch_count(c, s, p, base, span_pad, first, 0, c->stream));
+    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, false, c->stream));
     std::vector<unsigned long long> host(need);
     PSA_HIP(hipMemcpyAsync(host.data(), s.d_partial, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1228,9 +1265,10 @@ psa_status psa_debug_rescore(psa_context* c, const int32_t* offsets, int count, 
     for (int k = 0; k < count; ++k)
         if (offsets[k] < 0 || offsets[k] >= total) { set_last_error("psa_debug_rescore: offset out of range"); return PSA_ERR_ARG; }
     Scalars sc;
+    sc.global_best = 0;
     sc.cand_count = count;
     sc.done = 0;
-    sc.spare = 0;
+    s.inline_select = false;
     PSA_HIP(hipMemcpyAsync(s.d_scal, &sc, sizeof sc, hipMemcpyHostToDevice, c->stream));
     PSA_HIP(hipMemcpyAsync(s.d_cand, offsets, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, c->stream));
     PSA_TRY(launch_filter_back(c, s, 0, c->stream));

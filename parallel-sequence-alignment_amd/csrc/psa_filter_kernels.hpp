@@ -97,6 +97,25 @@ struct SlicedCounter {
     __device__ __forceinline__ void push(unsigned v) { push_level<0, T>(v); }
 };
 
+// ---- Seq2 queries of a batch: ASCII -> codes, all queries in one launch -------
+__global__ __launch_bounds__(256) void psa_encode_batch_kernel(const unsigned char* __restrict__ raw, int nq, int m,
+                                                               size_t in_stride, unsigned int* __restrict__ rows,
+                                                               unsigned char* __restrict__ bytes, int out_stride,
+                                                               int* __restrict__ bad)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int q = blockIdx.y;
+    if (i >= out_stride || q >= nq) return;
+    int code = kCodePad;
+    if (i < m) {
+        const unsigned char c = raw[(size_t)q * in_stride + i];
+        code = (c >= 'A' && c <= 'Z') ? c - 'A' : (c == '-' ? kCodeHyphen : kCodeBad);
+        if (code == kCodeBad) { atomicOr(bad, 2); code = kCodePad; }
+    }
+    rows[(size_t)q * out_stride + i] = (unsigned int)code;
+    bytes[(size_t)q * out_stride + i] = (unsigned char)code;
+}
+
 // ---- Seq1 class planes --------------------------------------------------------
 // For every Seq2 symbol b (row) and every 32 Seq1 positions (slot) the kernel
 // stores {lo, hi}: bit t of lo = class(Seq1[32*slot+t], b) in {'*','.'}, of hi =
@@ -269,10 +288,15 @@ struct CountArgs {
     int chunk_chars;  // chars per chunk (multiple of kUnroll * waves)
     int wave_chars;   // chars per wave   (multiple of kUnroll, <= kMaxWaveChars)
     int lds_slots;    // slots per staged row
-    int* zero;        // three ints cleared for the kernels behind this one (candidate count, arrivals, spare)
-    // single-chunk searches finish the counts here: bounds per offset + best pessimistic bound per tile
-    double*             upper;        // [span] or NULL (then `partial` is written and psa_keys_kernel runs)
-    unsigned long long* block_best;   // [gridDim.x]
+    // single-chunk searches finish here: score bounds per offset, running best pessimistic
+    // bound (atomic max), candidates = offsets whose optimistic bound reaches it
+    int inline_select;                // 0: write `partial`, psa_keys_kernel + psa_select_kernel follow
+    unsigned long long* global_best;  // ordered-u64, 0 before the search
+    int*                cand;         // [cap] absolute offsets
+    double*             cand_upper;   // [cap] their optimistic bounds (re-checked against the final best)
+    int*                cand_count;
+    int cap;
+    int first;                        // first offset of the searched range
     int lead;                         // offsets of tile 0 in front of the range (first - base)
     int span;
     BoundParams bounds;
@@ -288,7 +312,6 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     const int tile_o0 = a.base + blockIdx.x * kTile;           // absolute offset of word 0, bit 0 (multiple of 32)
     const int chunk_c0 = blockIdx.y * a.chunk_chars;           // first char of this chunk (multiple of 32)
     const int slot0 = (tile_o0 + chunk_c0) >> 5;               // first staged slot
-    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0 && a.zero) { a.zero[0] = 0; a.zero[1] = 0; a.zero[2] = 0; }
 
     // stage the 28 plane rows of the window [tile_o0+chunk_c0, +kTile+chunk_chars): rows dealt to waves
     for (int b = wave; b < kMaskRows; b += WAVES) {
@@ -403,7 +426,7 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
             for (int e = 0; e < kPer; ++e) n[k][e] |= ((v >> e) & 1u) << p;
         }
     }
-    if (a.upper == nullptr) {
+    if (!a.inline_select) {
         unsigned long long* dst = a.partial + (size_t)blockIdx.y * a.span_pad + (size_t)blockIdx.x * kTile + o_local;
 #pragma unroll
         for (int e = 0; e < kPer; ++e)
@@ -411,14 +434,15 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
         return;
     }
     // one chunk: the counts are final
+    double up[kPer];
     double pess = -INFINITY;
 #pragma unroll
     for (int e = 0; e < kPer; ++e) {
         const int o = (int)blockIdx.x * kTile + o_local + e - a.lead;      // relative to the range's first offset
+        up[e] = -INFINITY;
         if (o >= 0 && o < a.span) {
-            double up, pe;
-            offset_bounds(a.bounds, (int)n[0][e], (int)n[1][e], (int)n[2][e], up, pe);
-            a.upper[o] = up;
+            double pe;
+            offset_bounds(a.bounds, (int)n[0][e], (int)n[1][e], (int)n[2][e], up[e], pe);
             pess = fmax(pess, pe);
         }
     }
@@ -434,8 +458,22 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     __syncthreads();
     if (tid == 0) {
         for (int w = 1; w < WAVES; ++w) key = s_best[w] > key ? s_best[w] : key;
-        a.block_best[blockIdx.x] = key;
+        // running best over the tiles finished so far: a lower bound of the final best, so selecting
+        // against it keeps a superset of the true candidates (the re-score kernel re-checks)
+        const unsigned long long old = atomicMax(a.global_best, key);
+        s_best[WAVES] = old > key ? old : key;
     }
+    __syncthreads();
+    const double need = key_order(s_best[WAVES]);
+#pragma unroll
+    for (int e = 0; e < kPer; ++e)
+        if (up[e] >= need) {
+            const int slot = atomicAdd(a.cand_count, 1);
+            if (slot < a.cap) {
+                a.cand[slot] = a.first + (int)blockIdx.x * kTile + o_local + e - a.lead;
+                a.cand_upper[slot] = up[e];
+            }
+        }
 }
 
 // ---- keys (searches with several char chunks): counts -> score interval per offset
@@ -542,9 +580,11 @@ struct RescoreArgs {
     const unsigned char* sub;       // [32][32]
     const double*        delta_of_rank;
     const int*           cand;
-    const int*           cand_count;
+    const double*        cand_upper;  // optimistic bounds of the candidates, or NULL (already filtered)
+    unsigned long long*  global_best; // final best pessimistic bound (ordered-u64)
+    int*                 cand_count;
     CandRec*             rec;       // [cap]
-    int*                 done;      // arrival counter of the candidate workgroups (cleared by the count kernel)
+    int*                 done;      // arrival counter of the candidate workgroups
     SearchTail*          out;       // written by the last workgroup to arrive
     const int*           bad;       // the encode kernels' alphabet flag
     long long            pairs;
@@ -603,6 +643,9 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     if ((int)blockIdx.x >= count) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    // candidates were picked against a running best; drop those the final best rules out
+    const bool pruned = a.cand_upper != nullptr && a.cand_upper[blockIdx.x] < key_order(*a.global_best);
+    if (!pruned) {
     for (int k = tid; k < kRow * kRow; k += kRescoreThreads) s_clsrank[k] = a.clsrank[k];
     __syncthreads();
     const int o = a.cand[blockIdx.x];
@@ -767,6 +810,11 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
         }
         a.rec[blockIdx.x] = r;
     }
+    } else if (tid == 0) {
+        CandRec r;
+        r.score = 0.0; r.offset = -1; r.char_offset = -1; r.rank = 0; r.ch = 0;     // rank 0: ignored by the fold
+        a.rec[blockIdx.x] = r;
+    }
     // ---- the last candidate workgroup to finish folds all records (is_swapable order).
     // Hand-off per the release/acquire rule: record store -> agent-scope release ->
     // relaxed atomic arrival; the last arriver acquires before reading the records.
@@ -818,6 +866,10 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
             a.out->result = r;
             a.out->bad = *a.bad;
             a.out->overflow = total > a.cap ? 1 : 0;
+            // leave the search scalars clean for the next search on this slot
+            *a.cand_count = 0;
+            *a.done = 0;
+            *a.global_best = 0ull;
         }
     }
 }
