@@ -447,3 +447,24 @@ def test_batch_full_size_device_queries(psa):
         gold = {c_["name"]: c_ for c_ in json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))["cases"]}["c3_max"]
         assert (batch[0].offset, batch[0].char_offset, chr(batch[0].ch), "%.17g" % batch[0].score) == \
                (gold["offset"], gold["char_offset"], gold["ch"], gold["score"])
+
+
+def test_drop_in_program(psa, tmp_path):
+    """host/psa_main: ./input.txt -> ./output.txt byte-for-byte, the reference's stdout lines and exit codes
+    (main.c:13-56, cpu_funcs.c:25-121)."""
+    import shutil
+    import subprocess
+    from conftest import PKG
+    exe = os.path.join(PKG, "host", "psa_main")
+    assert os.path.exists(exe), "build() compiles the drop-in program"
+    shutil.copy(os.path.join(GOLDEN, "reference_input.txt"), tmp_path / "input.txt")
+    run = subprocess.run([exe, "100"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    assert (tmp_path / "output.txt").read_bytes() == open(os.path.join(GOLDEN, "reference_output.txt"), "rb").read()
+    lines = run.stdout.splitlines()
+    assert lines[0].startswith("threads=") and lines[1] == "CUDA percentage set to 100" and lines[2].startswith("total time: ")
+    # missing input -> "Error open input file" and exit code 2 (MPI_Abort(..., 2), cpu_funcs.c:38)
+    empty = tmp_path / "empty"
+    empty.mkdir()
+    run = subprocess.run([exe], cwd=empty, capture_output=True, text=True, timeout=60)
+    assert run.returncode == 2 and "Error open input file" in run.stdout
