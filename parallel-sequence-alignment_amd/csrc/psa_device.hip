@@ -385,6 +385,15 @@ struct psa_context {
     psa::SearchTail* h_tails = nullptr;   int tails_cap = 0;     // pinned, one per query of a batch (>= 1)
     unsigned int*  d_batch_rows = nullptr;   // codes of all queries of a batch
     unsigned char* d_batch_bytes = nullptr;  size_t batch_cap = 0;
+    // per-query search state of a batch (no buffer is reused inside a batch, so the main
+    // stream never has to wait for the re-score stream)
+    Scalars*         d_pool_scal = nullptr;
+    int*             d_pool_cand = nullptr;
+    double*          d_pool_cand_upper = nullptr;
+    psa::CandRec*    d_pool_rec = nullptr;
+    psa::SearchTail* d_pool_tail = nullptr;
+    int              pool_cap = 0;
+    std::vector<hipEvent_t> pool_events;
 
     SearchSlot  slot[kSlots];
 
@@ -825,7 +834,14 @@ psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hi
         r.fast_ok = ok && !chain_only;
         r.fast_min_exp = max_exp + 2;
     }
-    hipLaunchKernelGGL(psa::psa_rescore_kernel, dim3(kCandCap), dim3(psa::kRescoreThreads), 0, stream, r);
+    static bool granted = false;
+    if (!granted) {
+        PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_rescore_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, psa::kRescorePadLds));
+        granted = true;
+    }
+    hipLaunchKernelGGL(psa::psa_rescore_kernel, dim3(psa::kRescoreGrid), dim3(psa::kRescoreThreads),
+                       psa::kRescorePadLds, stream, r);
     PSA_HIP(hipGetLastError());
     return PSA_OK;
 }
@@ -853,6 +869,25 @@ psa_status check_ready(psa_context* c, int m, int first, int last)
     if (first < 0 || last > total || first >= last) {
         set_last_error("offset range must satisfy 0 <= first < last <= len(seq1)-len(seq2)+1");
         return PSA_ERR_ARG;
+    }
+    return PSA_OK;
+}
+
+psa_status ensure_pool(psa_context* c, int nq)
+{
+    if (nq > c->pool_cap) {
+        c->pool_cap = 0;
+        PSA_TRY(dev_alloc(&c->d_pool_scal, (size_t)nq));
+        PSA_TRY(dev_alloc(&c->d_pool_cand, (size_t)nq * kCandCap));
+        PSA_TRY(dev_alloc(&c->d_pool_cand_upper, (size_t)nq * kCandCap));
+        PSA_TRY(dev_alloc(&c->d_pool_rec, (size_t)nq * kCandCap));
+        PSA_TRY(dev_alloc(&c->d_pool_tail, (size_t)nq));
+        c->pool_cap = nq;
+    }
+    while ((int)c->pool_events.size() < nq) {
+        hipEvent_t ev;
+        PSA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        c->pool_events.push_back(ev);
     }
     return PSA_OK;
 }
@@ -967,6 +1002,12 @@ void psa_destroy(psa_context* c)
     for (auto& s : c->slot) free_slot(s);
     (void)hipFree(c->d_batch_rows);
     (void)hipFree(c->d_batch_bytes);
+    (void)hipFree(c->d_pool_scal);
+    (void)hipFree(c->d_pool_cand);
+    (void)hipFree(c->d_pool_cand_upper);
+    (void)hipFree(c->d_pool_rec);
+    (void)hipFree(c->d_pool_tail);
+    for (auto& ev : c->pool_events) (void)hipEventDestroy(ev);
     if (c->h_tails) (void)hipHostFree(c->h_tails);
     if (c->h_bad) (void)hipHostFree(c->h_bad);
     for (auto& ev : c->ev)
@@ -1119,14 +1160,32 @@ psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq
     hipLaunchKernelGGL(psa::psa_encode_batch_kernel, dim3((ostride + 255) / 256, nq), dim3(256), 0, c->stream,
                        base, nq, m, stride, c->d_batch_rows, c->d_batch_bytes, ostride, c->d_bad);
     PSA_HIP(hipGetLastError());
+    // single-chunk filter plans keep all per-query state in pools: nothing is reused inside the
+    // batch and the main stream runs count kernels back to back
+    FilterPlan plan;
+    const bool pooled = filter && plan_filter(first, last, m, &plan) && plan.nchunks == 1;
+    if (pooled) {
+        PSA_TRY(ensure_pool(c, nq));
+        PSA_HIP(hipMemsetAsync(c->d_pool_scal, 0, sizeof(Scalars) * (size_t)nq, c->stream));
+    }
     for (auto& s : c->slot) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
     // the aux stream must see everything already enqueued on the main stream (Seq1 planes, tables, codes)
     hipEvent_t& gate = c->slot[0].front_done;
     PSA_HIP(hipEventRecord(gate, c->stream));
     PSA_HIP(hipStreamWaitEvent(c->aux, gate, 0));
     for (int q = 0; q < nq; ++q) {
-        SearchSlot& s = c->slot[q % kSlots];
-        if (q >= kSlots) PSA_HIP(hipStreamWaitEvent(c->stream, s.back_done, 0));   // slot free again
+        SearchSlot view = c->slot[q % kSlots];     // pointers only; pooled queries override the small buffers
+        SearchSlot& s = pooled ? view : c->slot[q % kSlots];
+        if (pooled) {
+            view.d_scal = c->d_pool_scal + q;
+            view.d_cand = c->d_pool_cand + (size_t)q * kCandCap;
+            view.d_cand_upper = c->d_pool_cand_upper + (size_t)q * kCandCap;
+            view.d_rec = c->d_pool_rec + (size_t)q * kCandCap;
+            view.d_tail = c->d_pool_tail + q;
+            view.front_done = c->pool_events[q];
+        } else if (q >= kSlots) {
+            PSA_HIP(hipStreamWaitEvent(c->stream, s.back_done, 0));   // slot free again
+        }
         s.m = m;
         s.s2rows = c->d_batch_rows + (size_t)q * ostride;
         s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
@@ -1141,7 +1200,7 @@ psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq
             PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
         }
         PSA_HIP(hipMemcpyAsync(&c->h_tails[q], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->aux));
-        PSA_HIP(hipEventRecord(s.back_done, c->aux));
+        if (!pooled) PSA_HIP(hipEventRecord(s.back_done, c->aux));
     }
     PSA_HIP(hipStreamSynchronize(c->aux));
     PSA_HIP(hipStreamSynchronize(c->stream));

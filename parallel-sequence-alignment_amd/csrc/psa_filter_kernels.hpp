@@ -599,6 +599,8 @@ struct RescoreArgs {
 constexpr int kRescoreEpl = 8;          // chars per lane and batch on the integer walk
 constexpr int kRescoreThreads = 512;
 constexpr int kRescoreChunk = 32768;    // chars whose class codes are staged in LDS at a time
+constexpr int kRescoreGrid = 64;        // workgroups; each takes candidates ci = block, block + 64, ...
+constexpr int kRescorePadLds = 36 * 1024;   // + ~35 KB static: a rescore and a count workgroup never share a CU
 
 // Inclusive prefix sum of a 64-bit value over the 64 lanes, by DPP row shifts and row
 // broadcasts (register-to-register; no LDS round trips as __shfl_up would need).
@@ -638,17 +640,22 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     __shared__ double             s_vals[64];
     __shared__ long long          s_round[8];
     __shared__ unsigned long long s_key[kRescoreThreads / 64];
+    __shared__ int s_last;
+    extern __shared__ unsigned char s_pad[];      // never touched: only makes the workgroup too big to share a
+    (void)s_pad;                                  // CU with a count-kernel workgroup (LDS), see launch site
     int count = *a.cand_count;
     if (count > a.cap) count = a.cap;
-    if ((int)blockIdx.x >= count) return;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    // candidates were picked against a running best; drop those the final best rules out
-    const bool pruned = a.cand_upper != nullptr && a.cand_upper[blockIdx.x] < key_order(*a.global_best);
-    if (!pruned) {
+    if ((int)blockIdx.x >= count) return;
     for (int k = tid; k < kRow * kRow; k += kRescoreThreads) s_clsrank[k] = a.clsrank[k];
     __syncthreads();
-    const int o = a.cand[blockIdx.x];
+    const double final_best = key_order(*a.global_best);
+    for (int ci = blockIdx.x; ci < count; ci += gridDim.x) {
+    // candidates were picked against a running best; drop those the final best rules out
+    const bool pruned = a.cand_upper != nullptr && a.cand_upper[ci] < final_best;
+    if (!pruned) {
+    const int o = a.cand[ci];
     const unsigned char* s1 = a.s1 + o;
     const int m = a.m;
 
@@ -808,17 +815,16 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
             r.char_offset = -1;
             r.ch = 0;
         }
-        a.rec[blockIdx.x] = r;
+        a.rec[ci] = r;
     }
     } else if (tid == 0) {
         CandRec r;
         r.score = 0.0; r.offset = -1; r.char_offset = -1; r.rank = 0; r.ch = 0;     // rank 0: ignored by the fold
-        a.rec[blockIdx.x] = r;
+        a.rec[ci] = r;
     }
     // ---- the last candidate workgroup to finish folds all records (is_swapable order).
     // Hand-off per the release/acquire rule: record store -> agent-scope release ->
     // relaxed atomic arrival; the last arriver acquires before reading the records.
-    __shared__ int s_last;
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -830,8 +836,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
         }
     }
     __syncthreads();
-    if (!s_last || tid >= 64) return;
-    {
+    if (s_last && tid < 64) {
         const bool is_max = a.is_max != 0;
         const int total = *a.cand_count;
         double bs = is_max ? -INFINITY : INFINITY;
@@ -871,6 +876,8 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
             *a.done = 0;
             *a.global_best = 0ull;
         }
+    }
+    __syncthreads();            // the next candidate reuses the shared buffers
     }
 }
 
