@@ -94,8 +94,8 @@ __global__ void psa_encode_seq2(const unsigned char* __restrict__ raw, int m, un
         code = (c >= 'A' && c <= 'Z') ? c - 'A' : (c == '-' ? kCodeHyphen : kCodeBad);
         if (code == kCodeBad) { atomicOr(bad, 2); code = kCodePad; }
     }
-    rows[i] = (unsigned int)code;
-    bytes[i] = (unsigned char)code;
+    rows[i] = (unsigned int)code << kRowShift;    // symbol as a 4 KiB row offset (count kernel); the
+    bytes[i] = (unsigned char)code;               // sequential engine shifts it back to a table row
 }
 
 // ---------------------------------------------------------------------------
@@ -103,7 +103,7 @@ __global__ void psa_encode_seq2(const unsigned char* __restrict__ raw, int m, un
 // ---------------------------------------------------------------------------
 struct SeqArgs {
     const unsigned char* s1;      // codes, padded with kCodePad
-    const unsigned int*  s2rows;  // codes of Seq2, padded to a multiple of 4 with kCodePad
+    const unsigned int*  s2rows;  // Seq2 symbols << kRowShift, padded to a multiple of 4 with kCodePad
     const double*        pair;    // [32][32] fp64, [c2][c1]
     const unsigned char* rank;    // [32][32]
     const double*        delta_of_rank;  // [kMaxRanks]
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kBlock) void psa_seq_kernel(SeqArgs a)
         const unsigned int d1 = *reinterpret_cast<const unsigned int*>(p + i0 + 4);
         const uint4 rows = *reinterpret_cast<const uint4*>(a.s2rows + i0);   // wave-uniform -> scalar load
         const unsigned long long win = ((unsigned long long)d1 << 32) | d0;
-        const unsigned int row[4] = {rows.x, rows.y, rows.z, rows.w};
+        const unsigned int row[4] = {rows.x >> kRowShift, rows.y >> kRowShift, rows.z >> kRowShift, rows.w >> kRowShift};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
 #pragma unroll
@@ -240,14 +240,14 @@ __global__ __launch_bounds__(kBlock) void psa_finalize_kernel(FinalArgs a)
     }
     int mine = INT_MAX;
     for (int i = threadIdx.x; i < a.m; i += kBlock) {
-        const unsigned int idx = a.s2rows[i] * kRow + a.s1[w.offset + i];
+        const unsigned int idx = (a.s2rows[i] >> kRowShift) * kRow + a.s1[w.offset + i];
         if (a.rank[idx] == w.rank) { mine = i; break; }
     }
     atomicMin(&s_first_i, mine);
     __syncthreads();
     if (threadIdx.x == 0) {
         const int i = s_first_i;
-        const unsigned int idx = a.s2rows[i] * kRow + a.s1[w.offset + i];
+        const unsigned int idx = (a.s2rows[i] >> kRowShift) * kRow + a.s1[w.offset + i];
         psa_result r;
         r.score = w.score;
         r.offset = w.offset;
@@ -273,7 +273,7 @@ __global__ void psa_first_index_kernel(const unsigned char* __restrict__ s1, con
     int found = -1, ch = 0;
     if (want)
         for (int i = 0; i < m; ++i) {
-            const unsigned int idx = s2rows[i] * kRow + s1[o + i];
+            const unsigned int idx = (s2rows[i] >> kRowShift) * kRow + s1[o + i];
             if (rank[idx] == want) { found = i; ch = sub[idx]; break; }
         }
     char_offsets[o - first] = found;
@@ -621,7 +621,8 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
             const int wave_chars = chunk / waves;
             if (wave_chars > psa::kMaxWaveChars) continue;
             const int slots = chunk / 32 + 129;
-            int lds = psa::kMaskRows * slots * 8;
+            if (slots > psa::kRowSlots) continue;             // rows are kRowSlots slots apart in LDS
+            int lds = psa::kMaskRows * psa::kRowSlots * 8;
             if (exchange_bytes(waves) > lds) lds = exchange_bytes(waves);
             if (publish > lds) lds = publish;
             if (lds > kLdsLimit) continue;
@@ -684,7 +685,7 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
 {
     psa::CountArgs a;
     a.masks = c->d_masks;
-    a.s2 = s.s2bytes;
+    a.s2off = s.s2rows;
     a.partial = s.d_partial;
     a.nslots = c->nslots;
     a.base = base;

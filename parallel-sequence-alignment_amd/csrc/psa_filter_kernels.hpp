@@ -35,21 +35,19 @@ constexpr int kMaxWaveChars = 992; // multiple of kUnroll below 2^kPlanes
 constexpr int kMergedPlanes = 15;  // 16 waves x 1023 < 2^15
 constexpr int kMaskRows = 28;      // 27 symbols + the all-zero row of the padding symbol
 constexpr int kCounters = 3;       // n_lo, n_hi, n_both
+constexpr int kRowShift = 12;      // LDS rows of the count kernel are 4096 bytes apart (512 slots)
+constexpr int kRowSlots = 1 << (kRowShift - 3);
 
 // ---- carry-save arithmetic on 32 independent bit lanes ----------------------
 // v_bitop3_b32 (gfx950): any 3-input boolean function, full VALU rate
 // (v_bfi_b32 and v_alignbit_b32 issue at half rate: tools/ubench/valu_rate.hip).
 __device__ __forceinline__ unsigned xor3(unsigned a, unsigned b, unsigned c)
 {
-    unsigned d;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);
 }
 __device__ __forceinline__ unsigned maj3(unsigned a, unsigned b, unsigned c)
 {
-    unsigned d;
-    asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0xe8" : "=v"(d) : "v"(a), "v"(b), "v"(c));
-    return d;
+    return __builtin_amdgcn_bitop3_b32(a, b, c, 0xe8);
 }
 // full adder: sum -> a, carry returned
 __device__ __forceinline__ unsigned csa(unsigned& a, unsigned b, unsigned c)
@@ -112,7 +110,7 @@ __global__ __launch_bounds__(256) void psa_encode_batch_kernel(const unsigned ch
         code = (c >= 'A' && c <= 'Z') ? c - 'A' : (c == '-' ? kCodeHyphen : kCodeBad);
         if (code == kCodeBad) { atomicOr(bad, 2); code = kCodePad; }
     }
-    rows[(size_t)q * out_stride + i] = (unsigned int)code;
+    rows[(size_t)q * out_stride + i] = (unsigned int)code << kRowShift;   // symbol as a 4 KiB row offset
     bytes[(size_t)q * out_stride + i] = (unsigned char)code;
 }
 
@@ -194,28 +192,52 @@ __global__ __launch_bounds__(256) void psa_prepare_seq1_kernel(PrepareArgs a)
     for (int b = 0; b < kMaskRows; ++b) a.masks[(size_t)b * a.nslots + slot] = make_uint2(lo[b], hi[b]);
 }
 
+// ---- LDS reads of the count loop, issued one char ahead ------------------------
+// Four plain ds_read_b64 per char (slots l, l+1, l+64, l+65 of the symbol's row): 2 LDS cycles
+// each.  Left to the compiler they are merged into ds_read2_b64 pairs (8 cycles a pair) and
+// waited for right after issue; here they are issued for char J+1 before char J is processed
+// and retired by an explicit s_waitcnt (inline asm: hipcc does not count these loads, the wait
+// statement names every destination so no consumer can be scheduled above it).
+struct SlotRegs {
+    unsigned long long v[4];
+};
+
+__device__ __forceinline__ void lds_issue(SlotRegs& n, unsigned addr)
+{
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\t"
+                 "ds_read_b64 %2, %4 offset:512\n\tds_read_b64 %3, %4 offset:520"
+                 : "=&v"(n.v[0]), "=&v"(n.v[1]), "=&v"(n.v[2]), "=&v"(n.v[3])
+                 : "v"(addr));
+}
+
+__device__ __forceinline__ void lds_retire(SlotRegs& n)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n.v[0]), "+v"(n.v[1]), "+v"(n.v[2]), "+v"(n.v[3]));
+}
+
 // One char of the count loop: J is its index inside the round.  Tiles start on
 // a 32-offset boundary and rounds on a 32-char boundary, so the funnel shift of
 // char J is the compile-time constant J and all chars of a round read the same
 // slot column.  Lane l owns words l and l+64 of the tile: consecutive lanes read
-// consecutive 8-byte slots (conflict-free ds_read_b64).
+// consecutive 8-byte slots (conflict-free).  `cur` holds this char's slots; the
+// next char's are requested first (J == 31: char 0 of the next round, one column on).
 template <int J>
-__device__ __forceinline__ void count_step(SlicedCounter (&cnt)[2][kCounters],
-                                           const unsigned (&packed)[kUnroll / 4], const char* lds_lane,
-                                           int row_bytes)
+__device__ __forceinline__ void count_step(SlicedCounter (&cnt)[2][kCounters], SlotRegs& cur,
+                                           const unsigned (&rowoff)[kUnroll], unsigned next_rowoff,
+                                           unsigned lane_addr)
 {
-    const unsigned b = (packed[J >> 2] >> (8 * (J & 3))) & 0xffu;   // Seq2 symbol: wave-uniform
-    const uint2* src = reinterpret_cast<const uint2*>(lds_lane + b * row_bytes);
+    SlotRegs nxt;
+    // Seq2 symbol of the next char as a wave-uniform LDS row offset (symbol << kRowShift)
+    lds_issue(nxt, J + 1 < kUnroll ? lane_addr + rowoff[(J + 1) % kUnroll] : lane_addr + 8u + next_rowoff);
     unsigned lo0, hi0, lo1, hi1;
     if constexpr (J == 0) {
-        const uint2 s0 = src[0], s2 = src[64];
-        lo0 = s0.x; hi0 = s0.y; lo1 = s2.x; hi1 = s2.y;
+        lo0 = (unsigned)cur.v[0]; hi0 = (unsigned)(cur.v[0] >> 32);
+        lo1 = (unsigned)cur.v[2]; hi1 = (unsigned)(cur.v[2] >> 32);
     } else {
-        const uint2 s0 = src[0], s1 = src[1], s2 = src[64], s3 = src[65];
-        lo0 = __builtin_amdgcn_alignbit(s1.x, s0.x, J);
-        hi0 = __builtin_amdgcn_alignbit(s1.y, s0.y, J);
-        lo1 = __builtin_amdgcn_alignbit(s3.x, s2.x, J);
-        hi1 = __builtin_amdgcn_alignbit(s3.y, s2.y, J);
+        lo0 = __builtin_amdgcn_alignbit((unsigned)cur.v[1], (unsigned)cur.v[0], J);
+        hi0 = __builtin_amdgcn_alignbit((unsigned)(cur.v[1] >> 32), (unsigned)(cur.v[0] >> 32), J);
+        lo1 = __builtin_amdgcn_alignbit((unsigned)cur.v[3], (unsigned)cur.v[2], J);
+        hi1 = __builtin_amdgcn_alignbit((unsigned)(cur.v[3] >> 32), (unsigned)(cur.v[2] >> 32), J);
     }
     cnt[0][0].template push<J>(lo0);
     cnt[0][1].template push<J>(hi0);
@@ -223,14 +245,16 @@ __device__ __forceinline__ void count_step(SlicedCounter (&cnt)[2][kCounters],
     cnt[1][0].template push<J>(lo1);
     cnt[1][1].template push<J>(hi1);
     cnt[1][2].template push<J>(lo1 & hi1);
+    lds_retire(nxt);
+    cur = nxt;
 }
 
 template <int... Js>
-__device__ __forceinline__ void count_round(SlicedCounter (&cnt)[2][kCounters],
-                                            const unsigned (&packed)[kUnroll / 4], const char* lds_lane,
-                                            int row_bytes, std::integer_sequence<int, Js...>)
+__device__ __forceinline__ void count_round(SlicedCounter (&cnt)[2][kCounters], SlotRegs& cur,
+                                            const unsigned (&rowoff)[kUnroll], unsigned next_rowoff,
+                                            unsigned lane_addr, std::integer_sequence<int, Js...>)
 {
-    (count_step<Js>(cnt, packed, lds_lane, row_bytes), ...);
+    (count_step<Js>(cnt, cur, rowoff, next_rowoff, lane_addr), ...);
 }
 
 // ---- score interval of one offset from its exact counts ------------------------
@@ -280,7 +304,7 @@ __device__ __forceinline__ void offset_bounds(const BoundParams& b, int n_lo, in
 // ---- count kernel --------------------------------------------------------------
 struct CountArgs {
     const uint2*         masks;     // [kMaskRows][nslots]
-    const unsigned char* s2;        // codes of Seq2 as bytes, padded with kCodePad
+    const unsigned*      s2off;     // Seq2 symbols as LDS row offsets (code << kRowShift), padded with kCodePad
     unsigned long long*  partial;   // [nchunks][span_pad]: n_lo | n_hi<<21 | n_both<<42
     int nslots;
     int base;         // first offset of tile 0: the range's first offset rounded down to a multiple of 32
@@ -313,11 +337,24 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     const int chunk_c0 = blockIdx.y * a.chunk_chars;           // first char of this chunk (multiple of 32)
     const int slot0 = (tile_o0 + chunk_c0) >> 5;               // first staged slot
 
-    // stage the 28 plane rows of the window [tile_o0+chunk_c0, +kTile+chunk_chars): rows dealt to waves
+    // stage the 28 plane rows of the window [tile_o0+chunk_c0, +kTile+chunk_chars): rows dealt to the
+    // waves, all loads of a row in flight before the first LDS store
     for (int b = wave; b < kMaskRows; b += WAVES) {
         const uint2* src = a.masks + (size_t)b * a.nslots + slot0;
-        uint2* dst = lds + b * a.lds_slots;
-        for (int s = lane; s < a.lds_slots; s += 64) dst[s] = src[s];
+        uint2* dst = lds + b * kRowSlots;
+        for (int s0 = 0; s0 < a.lds_slots; s0 += 8 * 64) {
+            uint2 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int s = s0 + k * 64 + lane;
+                v[k] = s < a.lds_slots ? src[s] : make_uint2(0u, 0u);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int s = s0 + k * 64 + lane;
+                if (s < a.lds_slots) dst[s] = v[k];
+            }
+        }
     }
     __syncthreads();
 
@@ -328,17 +365,30 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
         for (int k = 0; k < kCounters; ++k) cnt[w][k].clear();
 
     const int c_begin = chunk_c0 + wave * a.wave_chars;
-    const unsigned* codes32 = reinterpret_cast<const unsigned*>(a.s2 + c_begin);
-    const int row_bytes = a.lds_slots * 8;
-    // slot column of this wave's first round; one column further per round
-    const char* lds_lane = reinterpret_cast<const char*>(lds) + lane * 8 + (size_t)((c_begin - chunk_c0) >> 5) * 8;
+    // constant address space: keeps these wave-uniform loads scalar (s_load) although the loop
+    // contains volatile asm
+    using const_u32 = const __attribute__((address_space(4))) unsigned;
+    const_u32* off32 = (const_u32*)(size_t)(a.s2off + c_begin);
+    // LDS byte address of this lane's slot in the column of the wave's first round; one column
+    // (8 bytes) further per round
+    unsigned lane_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds + (unsigned)lane * 8u +
+                         (unsigned)((c_begin - chunk_c0) >> 5) * 8u;
 
-    for (int g = 0; g < a.wave_chars; g += kUnroll) {
-        unsigned packed[kUnroll / 4];
+    // the row offsets of a round are fetched one round ahead, the LDS slots one char ahead;
+    // the last prefetches of a wave run past its range into valid padding and are never used
+    unsigned rowoff[kUnroll], rowoff_next[kUnroll];
 #pragma unroll
-        for (int q = 0; q < kUnroll / 4; ++q) packed[q] = codes32[(g >> 2) + q];   // wave-uniform
-        count_round(cnt, packed, lds_lane, row_bytes, std::make_integer_sequence<int, kUnroll>{});
-        lds_lane += 8;
+    for (int q = 0; q < kUnroll; ++q) rowoff[q] = off32[q];
+    SlotRegs cur;
+    lds_issue(cur, lane_addr + rowoff[0]);
+    lds_retire(cur);
+    for (int g = 0; g < a.wave_chars; g += kUnroll) {
+#pragma unroll
+        for (int q = 0; q < kUnroll; ++q) rowoff_next[q] = off32[g + kUnroll + q];   // wave-uniform
+        count_round(cnt, cur, rowoff, rowoff_next[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
+#pragma unroll
+        for (int q = 0; q < kUnroll; ++q) rowoff[q] = rowoff_next[q];
+        lane_addr += 8u;
     }
 
     // ---- epilogue: sum the WAVES partial counters (bit-sliced ripple adds through LDS),

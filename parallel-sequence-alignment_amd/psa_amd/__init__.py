@@ -19,7 +19,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpsa_amd.so")
+LIB_PATH = os.environ.get("PSA_AMD_LIB") or os.path.join(_HERE, "libpsa_amd.so")   # override: kernel experiments
 
 PSA_OK, PSA_ERR_ARG, PSA_ERR_ALPHABET, PSA_ERR_DEVICE, PSA_ERR_STATE = range(5)
 ENGINE_AUTO, ENGINE_SEQUENTIAL, ENGINE_FILTER = 0, 1, 2
