@@ -304,7 +304,7 @@ using psa::set_last_error;
 
 namespace {
 
-constexpr int kLdsLimit = 160 * 1024;
+constexpr int kLdsLimit = 160 * 1024 - 1024;   // dynamic LDS a workgroup may ask for (the kernels keep < 1 KB static)
 constexpr int kCandCap = 2048;        // candidates re-scored per search before falling back
 constexpr int kSeq1Slack = 49152;     // code-27 tail behind Seq1: tile + chunk rounding + staged-window over-read
 constexpr int kSeq2Slack = 32768 + 64;
@@ -373,7 +373,7 @@ struct psa_context {
 
     unsigned char* d_raw = nullptr;  size_t raw_cap = 0;   // staging for host sequences
     unsigned char* d_s1 = nullptr;        // Seq1 codes, code-27 padded to n_cap
-    uint2*         d_masks = nullptr;     int nslots = 0;   // Seq1 class planes
+    int            nslots = 0;            // 32-symbol slots of d_s1
     double*        d_pair = nullptr;
     unsigned char* d_rank = nullptr;
     unsigned char* d_sub = nullptr;
@@ -455,8 +455,7 @@ psa_status report_bad(psa_context* c)
     return PSA_ERR_ALPHABET;
 }
 
-// Seq1: symbol codes + the filter engine's class planes, one fused kernel
-// (the planes do not depend on the weights, only on the group tables).
+// Seq1: ASCII -> symbol codes (the class planes are built per workgroup inside the count kernel)
 psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
 {
     const int need = (n + kSeq1Slack + 63) & ~63;
@@ -464,14 +463,11 @@ psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
         PSA_TRY(dev_alloc(&c->d_s1, (size_t)need));
         c->n_cap = need;
         c->nslots = need / 32;
-        PSA_TRY(dev_alloc(&c->d_masks, (size_t)psa::kMaskRows * c->nslots));
     }
     c->n = -1;
     psa::PrepareArgs a;
     a.raw = static_cast<const unsigned char*>(d_raw);
     a.codes = c->d_s1;
-    a.masks = c->d_masks;
-    a.symbol_planes = c->d_symbol_planes;
     a.bad = c->d_bad;
     a.n = n;
     a.nslots = c->nslots;
@@ -684,10 +680,10 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
                         int span, bool inline_select, hipStream_t stream)
 {
     psa::CountArgs a;
-    a.masks = c->d_masks;
+    a.s1 = c->d_s1;
+    a.symbol_planes = c->d_symbol_planes;
     a.s2off = s.s2rows;
     a.partial = s.d_partial;
-    a.nslots = c->nslots;
     a.base = base;
     a.span_pad = span_pad;
     a.chunk_chars = p.chunk_chars;
@@ -992,7 +988,6 @@ void psa_destroy(psa_context* c)
     if (c->aux) (void)hipStreamSynchronize(c->aux);
     (void)hipFree(c->d_raw);
     (void)hipFree(c->d_s1);
-    (void)hipFree(c->d_masks);
     (void)hipFree(c->d_pair);
     (void)hipFree(c->d_rank);
     (void)hipFree(c->d_sub);

@@ -7,7 +7,7 @@
 // offset, with bit-sliced arithmetic.  The class of (Seq1[j], b) is stored as
 // two bit-planes over the Seq1 positions j, for each of the 27 symbols b:
 //
-//   lo[b][j] = class is '*' or '.'        hi[b][j] = class is ':' or '.'
+//   lo[b][j] = class is '*' or '.'        hi[b][j] = class is ':' or '.'   (built in LDS per workgroup)
 //   n_lo(o)   = sum_i lo[Seq2[i]][o+i]    (= n_star + n_dot)
 //   n_hi(o)   = sum_i hi[Seq2[i]][o+i]    (= n_colon + n_dot)
 //   n_both(o) = sum_i (lo & hi)[...]      (= n_dot)
@@ -114,42 +114,17 @@ __global__ __launch_bounds__(256) void psa_encode_batch_kernel(const unsigned ch
     bytes[(size_t)q * out_stride + i] = (unsigned char)code;
 }
 
-// ---- Seq1 class planes --------------------------------------------------------
-// For every Seq2 symbol b (row) and every 32 Seq1 positions (slot) the kernel
-// stores {lo, hi}: bit t of lo = class(Seq1[32*slot+t], b) in {'*','.'}, of hi =
-// class in {':','.'}.  symbol_planes[a] / [32+a] hold the same relation as a
-// column: bit b = lo / hi of (a, b); a thread fetches the 32 columns of its slot
-// and transposes the 32x32 bit matrix in registers.
+// ---- Seq1: ASCII -> symbol codes (32 positions per thread), alphabet validation ----
 struct PrepareArgs {
     const unsigned char* raw;         // Seq1 as ASCII (device), n bytes
     unsigned char*       codes;       // [32*nslots]: symbol codes, kCodePad behind n
-    uint2*               masks;       // [kMaskRows][nslots]
-    const unsigned*      symbol_planes;  // [64]
     int*                 bad;
     int                  n;
     int                  nslots;
 };
 
-__device__ __forceinline__ void transpose32(unsigned (&a)[32])
-{
-    // out[b] bit t = in[t] bit b  (recursive block swap, Hacker's Delight 7-3, mirrored)
-    unsigned m = 0x0000ffffu;
-#pragma unroll
-    for (int j = 16; j != 0; j >>= 1, m ^= (m << j)) {
-#pragma unroll
-        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
-            const unsigned t = ((a[k] >> j) ^ a[k + j]) & m;
-            a[k] ^= t << j;
-            a[k + j] ^= t;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void psa_prepare_seq1_kernel(PrepareArgs a)
 {
-    __shared__ unsigned s_planes[64];
-    if (threadIdx.x < 64) s_planes[threadIdx.x] = a.symbol_planes[threadIdx.x];
-    __syncthreads();
     const int slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= a.nslots) return;
     const int p0 = slot * 32;
@@ -170,26 +145,35 @@ __global__ __launch_bounds__(256) void psa_prepare_seq1_kernel(PrepareArgs a)
             w[q] = v;
         }
     }
-    unsigned lo[32], hi[32], cw[8];
+    unsigned cw[8];
     bool any_bad = false;
 #pragma unroll
     for (int t = 0; t < 32; ++t) {
         const unsigned c = (w[t >> 2] >> (8 * (t & 3))) & 0xffu;
-        unsigned code = c - 'A' < 26u ? c - 'A' : (c == '-' ? (unsigned)kCodeHyphen : (unsigned)kCodePad);
+        const unsigned code = c - 'A' < 26u ? c - 'A' : (c == '-' ? (unsigned)kCodeHyphen : (unsigned)kCodePad);
         if (code == (unsigned)kCodePad && p0 + t < a.n) any_bad = true;      // a real character outside [A-Z-]
         if ((t & 3) == 0) cw[t >> 2] = 0u;
         cw[t >> 2] |= code << (8 * (t & 3));
-        lo[t] = s_planes[code];
-        hi[t] = s_planes[32 + code];
     }
     if (any_bad) atomicOr(a.bad, 1);
     uint4* dst = reinterpret_cast<uint4*>(a.codes + p0);
     dst[0] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
     dst[1] = make_uint4(cw[4], cw[5], cw[6], cw[7]);
-    transpose32(lo);
-    transpose32(hi);
+}
+
+// out[b] bit t = in[t] bit b  (recursive block swap, Hacker's Delight 7-3, mirrored)
+__device__ __forceinline__ void transpose32(unsigned (&a)[32])
+{
+    unsigned m = 0x0000ffffu;
 #pragma unroll
-    for (int b = 0; b < kMaskRows; ++b) a.masks[(size_t)b * a.nslots + slot] = make_uint2(lo[b], hi[b]);
+    for (int j = 16; j != 0; j >>= 1, m ^= (m << j)) {
+#pragma unroll
+        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
+            const unsigned t = ((a[k] >> j) ^ a[k + j]) & m;
+            a[k] ^= t << j;
+            a[k + j] ^= t;
+        }
+    }
 }
 
 // ---- LDS reads of the count loop, issued one char ahead ------------------------
@@ -303,10 +287,10 @@ __device__ __forceinline__ void offset_bounds(const BoundParams& b, int n_lo, in
 
 // ---- count kernel --------------------------------------------------------------
 struct CountArgs {
-    const uint2*         masks;     // [kMaskRows][nslots]
+    const unsigned char* s1;        // Seq1 symbol codes, padded with kCodePad (32 per slot)
+    const unsigned*      symbol_planes;  // [64]: class planes of every Seq1 symbol over the Seq2 symbols
     const unsigned*      s2off;     // Seq2 symbols as LDS row offsets (code << kRowShift), padded with kCodePad
     unsigned long long*  partial;   // [nchunks][span_pad]: n_lo | n_hi<<21 | n_both<<42
-    int nslots;
     int base;         // first offset of tile 0: the range's first offset rounded down to a multiple of 32
     int span_pad;     // offsets covered = ntiles*kTile
     int chunk_chars;  // chars per chunk (multiple of kUnroll * waves)
@@ -337,24 +321,29 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     const int chunk_c0 = blockIdx.y * a.chunk_chars;           // first char of this chunk (multiple of 32)
     const int slot0 = (tile_o0 + chunk_c0) >> 5;               // first staged slot
 
-    // stage the 28 plane rows of the window [tile_o0+chunk_c0, +kTile+chunk_chars): rows dealt to the
-    // waves, all loads of a row in flight before the first LDS store
-    for (int b = wave; b < kMaskRows; b += WAVES) {
-        const uint2* src = a.masks + (size_t)b * a.nslots + slot0;
-        uint2* dst = lds + b * kRowSlots;
-        for (int s0 = 0; s0 < a.lds_slots; s0 += 8 * 64) {
-            uint2 v[8];
+    // Build the class planes of the window [tile_o0+chunk_c0, +kTile+chunk_chars) in LDS: row b
+    // (Seq2 symbol), slot s holds {lo, hi}: bit t of lo = class(Seq1[32*(slot0+s)+t], b) in
+    // {'*','.'}, of hi = class in {':','.'}.  A thread fetches the 32 symbol columns of its slot
+    // (symbol_planes: bit b = the relation of that Seq1 symbol to b) and transposes the two 32x32
+    // bit matrices in registers — 14 KB of codes read per workgroup instead of 100 KB of planes.
+    __shared__ unsigned s_planes[64];
+    if (tid < 64) s_planes[tid] = a.symbol_planes[tid];
+    __syncthreads();
+    for (int slot = tid; slot < a.lds_slots; slot += WAVES * 64) {
+        const uint4* src = reinterpret_cast<const uint4*>(a.s1 + ((size_t)(slot0 + slot) << 5));
+        const uint4 c0 = src[0], c1 = src[1];
+        const unsigned w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        unsigned lo[32], hi[32];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int s = s0 + k * 64 + lane;
-                v[k] = s < a.lds_slots ? src[s] : make_uint2(0u, 0u);
-            }
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int s = s0 + k * 64 + lane;
-                if (s < a.lds_slots) dst[s] = v[k];
-            }
+        for (int t = 0; t < 32; ++t) {
+            const unsigned code = (w[t >> 2] >> (8 * (t & 3))) & 0xffu;
+            lo[t] = s_planes[code];
+            hi[t] = s_planes[32 + code];
         }
+        transpose32(lo);
+        transpose32(hi);
+#pragma unroll
+        for (int b = 0; b < kMaskRows; ++b) lds[b * kRowSlots + slot] = make_uint2(lo[b], hi[b]);
     }
     __syncthreads();
 

@@ -13,6 +13,11 @@
  * argv[1] (CUDA percentage, main.c:30-42) is accepted; every offset runs on
  * the GPU here (there is no CPU search path in this program), so the value
  * only changes the printed line when it is a valid percentage.
+ *
+ * Extension: `psa_main --all` reads EVERY stacked 7-token
+ * record of input.txt (the reference's file holds 15, it only ever reads the
+ * first) and writes one "<mutated seq2>\n<offset> <score>" block per record,
+ * blocks separated by a newline.
  */
 #include <math.h>
 #include <stdio.h>
@@ -39,6 +44,50 @@ static int read_token(FILE* f, char* dst, size_t cap)
 
 static ProgramData g_data;   /* ~1 MB: kept off the stack */
 
+static int run_all_records(void)
+{
+    FILE* in = fopen(PSA_INPUT_FILE, "r");
+    FILE* out;
+    static char mut[PSA_SEQ2_MAX_LEN];
+    char word[16];
+    int records = 0;
+    if (!in) {
+        printf("Error open input file `%s`\n", PSA_INPUT_FILE);
+        return 2;
+    }
+    out = fopen(PSA_OUTPUT_FILE, "w");
+    if (!out) {
+        printf("Error open or write to the output file %s\n", PSA_OUTPUT_FILE);
+        fclose(in);
+        return 2;
+    }
+    while (fscanf(in, "%lf %lf %lf %lf", &g_data.weights[0], &g_data.weights[1], &g_data.weights[2],
+                  &g_data.weights[3]) == 4) {
+        Mutant mutant;
+        double score;
+        int total_offsets;
+        if (read_token(in, g_data.seq1, sizeof g_data.seq1) != 1 || read_token(in, g_data.seq2, sizeof g_data.seq2) != 1 ||
+            read_token(in, word, sizeof word) != 1)
+            break;
+        g_data.is_max = strcmp(word, PSA_MAXIMUM_STR) == 0 ? 1 : 0;
+        total_offsets = (int)strlen(g_data.seq1) - (int)strlen(g_data.seq2) + 1;
+        if (total_offsets < 1 || g_data.seq2[0] == '\0') break;
+        score = gpu_run_program(&g_data, &mutant, 0, total_offsets);
+        strcpy(mut, g_data.seq2);
+        if (mutant.char_offset >= 0) mut[mutant.char_offset] = mutant.ch;
+        fprintf(out, "%s%s\n%d %g", records ? "\n" : "", mut, mutant.offset, score);
+        records++;
+    }
+    fclose(in);
+    fclose(out);
+    if (!records) {
+        printf("Error reading input file `%s`\n", PSA_INPUT_FILE);
+        return 2;
+    }
+    printf("records: %d\n", records);
+    return 0;
+}
+
 int main(int argc, char* argv[])
 {
     FILE* in;
@@ -51,6 +100,7 @@ int main(int argc, char* argv[])
     struct timespec t0, t1;
     static char mut[PSA_SEQ2_MAX_LEN];
 
+    if (argc == 2 && strcmp(argv[1], "--all") == 0) return run_all_records();
     if (argc == 2) {
         int v = atoi(argv[1]);
         if (v >= 0 && v <= 100) cuda_percentage = v;

@@ -468,3 +468,43 @@ def test_drop_in_program(psa, tmp_path):
     empty.mkdir()
     run = subprocess.run([exe], cwd=empty, capture_output=True, text=True, timeout=60)
     assert run.returncode == 2 and "Error open input file" in run.stdout
+
+
+def test_long_seq2_multi_chunk_path(psa, oracle):
+    """|Seq2| above one workgroup's reach (16 waves x 992 chars): several char chunks, partial counts
+    combined by psa_keys_kernel / psa_select_kernel; also a short range that spreads chunks to fill the GPU."""
+    s1 = psa.generate_sequence(91, 60000)
+    s2 = psa.generate_sequence(92, 20011)
+    for is_max in (True, False):
+        with psa.Context(0) as c:
+            c.set_engine(psa.ENGINE_FILTER)
+            c.set_weights(W_README, is_max)
+            c.set_seq1(s1)
+            c.set_seq2(s2)
+            assert_same(c.search(), oracle.search(s1, s2, W_README, is_max, threads=8))
+            got = c.debug_counts(7, 9000)
+            want = _class_counts_numpy(psa, s1, s2, W_README, is_max, 7, 9000)
+            for k in range(3):
+                assert np.array_equal(got[k].astype(np.int64), want[k])
+            batch = c.search_batch([s2, psa.generate_sequence(93, 20011)])
+            assert_same(batch[0], oracle.search(s1, s2, W_README, is_max, threads=8))
+            assert c.fallback_count() == 0
+
+
+def test_drop_in_program_all_records(psa, oracle, reference_records, tmp_path):
+    """psa_main --all: every stacked record of the reference's input.txt == the oracle."""
+    import shutil
+    import subprocess
+    from conftest import PKG
+    exe = os.path.join(PKG, "host", "psa_main")
+    shutil.copy(os.path.join(GOLDEN, "reference_input.txt"), tmp_path / "input.txt")
+    run = subprocess.run([exe, "--all"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    lines = (tmp_path / "output.txt").read_text().split("\n")
+    assert len(lines) == 2 * len(reference_records) == 30
+    for k, (w, s1, s2, is_max) in enumerate(reference_records):
+        score, off, ci, ch = oracle.search(s1, s2, w, is_max, threads=8)
+        mut = bytearray(s2)
+        mut[ci] = ord(ch)
+        assert lines[2 * k] == mut.decode()
+        assert lines[2 * k + 1] == "%d %s" % (off, "%g" % score)
