@@ -31,6 +31,8 @@ struct SearchTail {   // everything the host reads back after a search, one D2H 
     psa_result result;
     int        bad;       // alphabet flag of the encode kernels (bit 0 seq1, bit 1 seq2)
     int        overflow;  // filter engine: the candidate list did not fit
+    int        seq;       // echo of the search's sequence number: proves this tail belongs to it
+    int        pad;
 };
 
 struct BlockRec {     // per-block / per-shard arg-best
@@ -200,6 +202,7 @@ struct FinalArgs {
     const int*           bad;
     int m;
     int is_max;
+    int seq;
     long long pairs;
 };
 
@@ -235,6 +238,7 @@ __global__ __launch_bounds__(kBlock) void psa_finalize_kernel(FinalArgs a)
             a.out->result = r;
             a.out->bad = *a.bad;
             a.out->overflow = 0;
+            a.out->seq = a.seq;
         }
         return;
     }
@@ -258,6 +262,7 @@ __global__ __launch_bounds__(kBlock) void psa_finalize_kernel(FinalArgs a)
         a.out->result = r;
         a.out->bad = *a.bad;
         a.out->overflow = 0;
+        a.out->seq = a.seq;
     }
 }
 
@@ -345,6 +350,7 @@ struct SearchSlot {
     const unsigned int*  s2rows = nullptr;     // the codes this slot searches: its own buffers, or one
     const unsigned char* s2bytes = nullptr;    // query of the batch buffer
     bool                inline_select = false; // the count kernel picked the candidates itself
+    bool                scal_dirty = false;    // a filter search was enqueued and its self-reset not confirmed yet
     psa::BlockRec*      d_blocks = nullptr;    int blocks_cap = 0;      // sequential engine
     unsigned long long* d_partial = nullptr;   size_t partial_cap = 0;
     double*             d_upper = nullptr;     size_t upper_cap = 0;
@@ -410,6 +416,7 @@ struct psa_context {
     double      sum_search_ms = 0.0, sum_kernel_ms = 0.0;   // over profiled searches since profiling was switched on
     int         profiled = 0;
     int         fallbacks = 0;               // filter searches that overflowed into the sequential engine
+    int         seq = 0;                     // sequence number of the last search enqueued
 };
 
 namespace {
@@ -584,6 +591,7 @@ psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last,
     f.bad = c->d_bad;
     f.m = s.m;
     f.is_max = c->tables.is_max;
+    f.seq = c->seq;
     f.pairs = (long long)span * (long long)s.m;
     hipLaunchKernelGGL(psa::psa_finalize_kernel, dim3(1), dim3(psa::kBlock), 0, stream, f);
     PSA_HIP(hipGetLastError());
@@ -807,6 +815,7 @@ psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hi
     r.out = s.d_tail;
     r.bad = c->d_bad;
     r.pairs = pairs;
+    r.seq = c->seq;
     r.class_value[0] = t.weights[0];       // get_weight, cuda_funcs.cu:442-452
     r.class_value[1] = -t.weights[1];
     r.class_value[2] = -t.weights[2];
@@ -1074,12 +1083,16 @@ psa_status psa_search_async(psa_context* c, int first, int last)
     PSA_TRY(check_ready(c, s.m, first, last));
     PSA_TRY(ensure_device(c));
     c->timing_valid = false;
+    c->seq += 1;
     if (c->profiling) PSA_HIP(hipEventRecord(c->ev[0], c->stream));
     c->pending_filter = use_filter(c, first, last, s.m);
     c->pending_first = first;
     c->pending_last = last;
     if (c->pending_filter) {
-        PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));   // normally already clean (self-resetting)
+        // the re-score kernel's last workgroup leaves the scalars zeroed; only a search that was
+        // enqueued but never waited for (or failed) can have left them dirty
+        if (s.scal_dirty) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
+        s.scal_dirty = true;
         PSA_TRY(launch_filter_front(c, s, first, last, c->stream, c->profiling));
         PSA_TRY(launch_filter_back(c, s, (long long)(last - first) * s.m, c->stream));
     } else {
@@ -1100,12 +1113,19 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
     if (!c->pending) { set_last_error("psa_search_wait: no search in flight"); return PSA_ERR_STATE; }
     PSA_HIP(hipStreamSynchronize(c->stream));
     c->pending = false;
+    c->slot[0].scal_dirty = false;            // the search ran to its end: scalars are zero again
     *c->h_bad = c->h_tails[0].bad;
     PSA_TRY(report_bad(c));                   // device-resident sequences are validated here
-    if (c->pending_filter && c->h_tails[0].overflow) {
+    // overflow: more near-tied offsets than the candidate list holds.  A tail that does not echo
+    // this search's number means no candidate workgroup ran (cannot happen for finite scores);
+    // both are answered by the sequential engine.
+    const bool stale = c->h_tails[0].seq != c->seq;
+    if (stale) c->slot[0].scal_dirty = true;
+    if (c->pending_filter && (c->h_tails[0].overflow || stale)) {
         // more near-tied offsets than the candidate list holds (e.g. a homopolymer):
         // score every offset in reference order instead
         c->fallbacks += 1;
+        c->seq += 1;
         PSA_TRY(launch_sequential(c, c->slot[0], c->pending_first, c->pending_last, nullptr, nullptr, c->stream));
         PSA_HIP(hipMemcpyAsync(&c->h_tails[0], c->slot[0].d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
         PSA_HIP(hipStreamSynchronize(c->stream));
@@ -1145,6 +1165,7 @@ psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq
     const unsigned char* base = static_cast<const unsigned char*>(d_queries);
     const bool filter = use_filter(c, first, last, m);
     const long long pairs = (long long)(last - first) * m;
+    const int seq0 = c->seq + 1;       // query q carries sequence number seq0 + q
     // all queries encoded by one launch: [nq][ostride] codes as u32 rows and as bytes
     const int ostride = (m + kSeq2Slack + 63) & ~63;
     if ((size_t)nq * ostride > c->batch_cap) {
@@ -1185,6 +1206,7 @@ psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq
         s.m = m;
         s.s2rows = c->d_batch_rows + (size_t)q * ostride;
         s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
+        c->seq = seq0 + q;
         if (filter) {
             PSA_TRY(launch_filter_front(c, s, first, last, c->stream, false));
             PSA_HIP(hipEventRecord(s.front_done, c->stream));
@@ -1205,9 +1227,11 @@ psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq
     *c->h_bad = bad;
     PSA_TRY(report_bad(c));
     for (int q = 0; q < nq; ++q) {
-        if (filter && c->h_tails[q].overflow) {
+        if (filter && (c->h_tails[q].overflow || c->h_tails[q].seq != seq0 + q)) {
             SearchSlot& s = c->slot[0];
             c->fallbacks += 1;
+            c->seq += 1;
+            for (auto& sl : c->slot) sl.scal_dirty = true;
             s.m = m;
             s.s2rows = c->d_batch_rows + (size_t)q * ostride;
             s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;

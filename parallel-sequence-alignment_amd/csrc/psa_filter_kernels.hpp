@@ -627,6 +627,7 @@ struct RescoreArgs {
     SearchTail*          out;       // written by the last workgroup to arrive
     const int*           bad;       // the encode kernels' alphabet flag
     long long            pairs;
+    int                  seq;       // sequence number of the search, echoed in the tail
     double class_value[8];          // pair score of class 0..3, +0.0 for the padding class 4
     int m;
     int cap;
@@ -910,6 +911,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
             a.out->result = r;
             a.out->bad = *a.bad;
             a.out->overflow = total > a.cap ? 1 : 0;
+            a.out->seq = a.seq;
             // leave the search scalars clean for the next search on this slot
             *a.cand_count = 0;
             *a.done = 0;

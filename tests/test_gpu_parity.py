@@ -508,3 +508,36 @@ def test_drop_in_program_all_records(psa, oracle, reference_records, tmp_path):
         mut[ci] = ord(ch)
         assert lines[2 * k] == mut.decode()
         assert lines[2 * k + 1] == "%d %s" % (off, "%g" % score)
+
+
+def test_randomised_small_problems_all_engines(psa, oracle):
+    """Many small random problems (lengths, alphabets, weights, modes, sub-ranges): sequential engine,
+    filter engine and the batch path all equal the oracle; the filter engine reuses one context throughout
+    (its search scalars must come back clean after every search, including fallbacks)."""
+    rng = np.random.default_rng(2024)
+    alphabets = [b"ACDEFGHIKLMNPQRSTVWY", b"ABCDEFGHIJKLMNOPQRSTUVWXYZ", b"AL", b"NDEQK-", b"STA-MILV"]
+    with psa.Context(0) as cf, psa.Context(0) as cs:
+        cf.set_engine(psa.ENGINE_FILTER)
+        cs.set_engine(psa.ENGINE_SEQUENTIAL)
+        for trial in range(60):
+            alpha = np.frombuffer(alphabets[trial % len(alphabets)], np.uint8)
+            m = int(rng.integers(1, 400))
+            n = m + int(rng.integers(0, 6000))
+            s1 = rng.choice(alpha, n).tobytes()
+            s2 = rng.choice(alpha, m).tobytes()
+            w = [float(x) for x in rng.choice([0.0, 0.1, 0.25, 0.5, 1.0, 1.5, 2.6, 3.0, 13.7], 4)]
+            is_max = bool(trial & 1)
+            total = n - m + 1
+            first = int(rng.integers(0, total))
+            last = int(rng.integers(first + 1, total + 1))
+            want_full = oracle.search(s1, s2, w, is_max, threads=4)
+            want_sub = oracle.search(s1, s2, w, is_max, first, last, threads=4)
+            for c in (cf, cs):
+                c.set_weights(w, is_max)
+                c.set_seq1(s1)
+                c.set_seq2(s2)
+                assert_same(c.search(), want_full)
+                assert_same(c.search(first, last), want_sub)
+            got = cf.search_batch([s2, s2[::-1]], first, last)
+            assert_same(got[0], want_sub)
+            assert_same(got[1], oracle.search(s1, s2[::-1], w, is_max, first, last, threads=4))
