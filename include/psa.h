@@ -115,6 +115,19 @@ psa_status psa_search_batch(psa_context* ctx, const char* queries, int nq, int m
 psa_status psa_search_batch_device(psa_context* ctx, const void* d_queries, int nq, int m, size_t stride,
                                    int first_offset, int last_offset, psa_result* results);
 
+/* MIN and MAX of every query in one pass (configs[4] "MIN+MAX"): what two batches with the
+ * context's weights and is_max = 1 / 0 would return (the reference runs its program once per
+ * mode: one maximum/minimum line per input.txt, cpu_funcs.c:365).  The sign class of a char
+ * pair does not depend on the mode, so both searches of a query share the class-count pass;
+ * bounds, candidates and the exact re-score are per mode.  The context's own mode is
+ * unchanged by the call. */
+psa_status psa_search_batch_minmax(psa_context* ctx, const char* queries, int nq, int m, size_t stride,
+                                   int first_offset, int last_offset, psa_result* results_max,
+                                   psa_result* results_min);
+psa_status psa_search_batch_minmax_device(psa_context* ctx, const void* d_queries, int nq, int m, size_t stride,
+                                          int first_offset, int last_offset, psa_result* results_max,
+                                          psa_result* results_min);
+
 /* Per-offset view for tests: scores[o-first] = total+diff of offset o,
  * char_offsets / chs the chosen substitution (find_best_mutant_offset,
  * cpu_funcs.c:257-300).  Arrays are host memory of last-first entries; any

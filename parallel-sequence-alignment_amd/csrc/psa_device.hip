@@ -370,6 +370,10 @@ struct psa_context {
     int         device = 0;
     hipStream_t stream = nullptr;      // main stream (caller's or owned)
     hipStream_t aux = nullptr;         // owned: tails of batched searches
+    hipStream_t twin = nullptr;        // owned: every other count kernel of a pooled batch (kernels overlap at their edges)
+    int batch_streams = 2;
+    int batch_rescore_grid = 8;        // re-score workgroups per query inside a batch (the CUs are busy counting)
+    bool rescore_pad = true;
     bool        own_stream = false;
 
     psa::Tables tables;
@@ -386,6 +390,13 @@ struct psa_context {
     double*        d_delta = nullptr;
     unsigned*      d_symbol_planes = nullptr;
     unsigned char* d_clsrank = nullptr;   // class | rank << 3 per pair (rescore kernel)
+    // the same weights in the opposite mode (MIN+MAX batches); built on first use
+    psa::Tables    alt_tables;
+    bool           have_alt = false;
+    unsigned char* d_alt_rank = nullptr;
+    unsigned char* d_alt_sub = nullptr;
+    double*        d_alt_delta = nullptr;
+    unsigned char* d_alt_clsrank = nullptr;
     int*           d_bad = nullptr;
     int*           h_bad = nullptr;       // pinned
     psa::SearchTail* h_tails = nullptr;   int tails_cap = 0;     // pinned, one per query of a batch (>= 1)
@@ -427,17 +438,63 @@ psa_status ensure_device(psa_context* c)
     return PSA_OK;
 }
 
+// The tables of one search mode: the context's own (psa_set_weights) or the opposite mode's.
+// The pair-score table d_pair depends on the weights only and is shared.
+struct TableSet {
+    const psa::Tables*   t;
+    const unsigned char* d_rank;
+    const unsigned char* d_sub;
+    const double*        d_delta;
+    const unsigned char* d_clsrank;
+};
+
+TableSet primary_tables(const psa_context* c)
+{
+    return TableSet{&c->tables, c->d_rank, c->d_sub, c->d_delta, c->d_clsrank};
+}
+
+TableSet alternate_tables(const psa_context* c)
+{
+    return TableSet{&c->alt_tables, c->d_alt_rank, c->d_alt_sub, c->d_alt_delta, c->d_alt_clsrank};
+}
+
+psa_status upload_mode_tables(psa_context* c, const psa::Tables& t, unsigned char* d_rank, unsigned char* d_sub,
+                              double* d_delta, unsigned char* d_clsrank)
+{
+    PSA_HIP(hipMemcpyAsync(d_rank, t.rank, sizeof t.rank, hipMemcpyHostToDevice, c->stream));
+    PSA_HIP(hipMemcpyAsync(d_sub, t.sub, sizeof t.sub, hipMemcpyHostToDevice, c->stream));
+    PSA_HIP(hipMemcpyAsync(d_delta, t.delta_of_rank, sizeof t.delta_of_rank, hipMemcpyHostToDevice, c->stream));
+    unsigned char clsrank[psa::kRow * psa::kRow];
+    for (int k = 0; k < psa::kRow * psa::kRow; ++k) clsrank[k] = (unsigned char)(t.cls[k] | (t.rank[k] << 3));
+    PSA_HIP(hipMemcpyAsync(d_clsrank, clsrank, sizeof clsrank, hipMemcpyHostToDevice, c->stream));
+    PSA_HIP(hipStreamSynchronize(c->stream));   // host arrays go out of scope right after return
+    return PSA_OK;
+}
+
 psa_status upload_tables(psa_context* c)
 {
     const psa::Tables& t = c->tables;
     PSA_HIP(hipMemcpyAsync(c->d_pair, t.pair, sizeof t.pair, hipMemcpyHostToDevice, c->stream));
-    PSA_HIP(hipMemcpyAsync(c->d_rank, t.rank, sizeof t.rank, hipMemcpyHostToDevice, c->stream));
-    PSA_HIP(hipMemcpyAsync(c->d_sub, t.sub, sizeof t.sub, hipMemcpyHostToDevice, c->stream));
-    PSA_HIP(hipMemcpyAsync(c->d_delta, t.delta_of_rank, sizeof t.delta_of_rank, hipMemcpyHostToDevice, c->stream));
-    unsigned char clsrank[psa::kRow * psa::kRow];
-    for (int k = 0; k < psa::kRow * psa::kRow; ++k) clsrank[k] = (unsigned char)(t.cls[k] | (t.rank[k] << 3));
-    PSA_HIP(hipMemcpyAsync(c->d_clsrank, clsrank, sizeof clsrank, hipMemcpyHostToDevice, c->stream));
-    PSA_HIP(hipStreamSynchronize(c->stream));   // host arrays go out of scope right after return
+    return upload_mode_tables(c, t, c->d_rank, c->d_sub, c->d_delta, c->d_clsrank);
+}
+
+// tables of the opposite mode for the same weights
+psa_status ensure_alt_tables(psa_context* c)
+{
+    if (c->have_alt) return PSA_OK;
+    std::string err;
+    if (!psa::build_tables(c->tables.weights, c->tables.is_max ? 0 : 1, &c->alt_tables, &err)) {
+        set_last_error(err);
+        return PSA_ERR_ARG;
+    }
+    if (!c->d_alt_rank) {
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_alt_rank), psa::kRow * psa::kRow));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_alt_sub), psa::kRow * psa::kRow));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_alt_clsrank), psa::kRow * psa::kRow));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_alt_delta), sizeof(double) * psa::kMaxRanks));
+    }
+    PSA_TRY(upload_mode_tables(c, c->alt_tables, c->d_alt_rank, c->d_alt_sub, c->d_alt_delta, c->d_alt_clsrank));
+    c->have_alt = true;
     return PSA_OK;
 }
 
@@ -534,7 +591,7 @@ int pick_r(const psa_context* c, int span)
 }
 
 psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last, double* per_score,
-                             unsigned char* per_rank, hipStream_t stream)
+                             unsigned char* per_rank, hipStream_t stream, const TableSet& ts)
 {
     const int span = last - first;
     const int r = pick_r(c, span);
@@ -550,8 +607,8 @@ psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last,
     a.s1 = c->d_s1;
     a.s2rows = s.s2rows;
     a.pair = c->d_pair;
-    a.rank = c->d_rank;
-    a.delta_of_rank = c->d_delta;
+    a.rank = ts.d_rank;
+    a.delta_of_rank = ts.d_delta;
     a.block_out = s.d_blocks;
     a.per_score = per_score;
     a.per_rank = per_rank;
@@ -560,7 +617,7 @@ psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last,
     a.first = first;
     a.last = last;
     a.base = base;
-    a.is_max = c->tables.is_max;
+    a.is_max = ts.t->is_max;
 
     if (c->profiling) PSA_HIP(hipEventRecord(c->ev[2], stream));
     switch (r) {
@@ -585,12 +642,12 @@ psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last,
     f.nblocks = nblocks;
     f.s1 = c->d_s1;
     f.s2rows = s.s2rows;
-    f.rank = c->d_rank;
-    f.sub = c->d_sub;
+    f.rank = ts.d_rank;
+    f.sub = ts.d_sub;
     f.out = s.d_tail;
     f.bad = c->d_bad;
     f.m = s.m;
-    f.is_max = c->tables.is_max;
+    f.is_max = ts.t->is_max;
     f.seq = c->seq;
     f.pairs = (long long)span * (long long)s.m;
     hipLaunchKernelGGL(psa::psa_finalize_kernel, dim3(1), dim3(psa::kBlock), 0, stream, f);
@@ -654,29 +711,28 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
     return found;
 }
 
-double filter_slack(const psa_context* c, int m)
+double filter_slack(const psa::Tables& t, int m)
 {
     // |sequential fp64 sum - exact sum| <= (m-1) u sum|p_i| / (1 - (m-1) u)   (u = 2^-53),
     // the count formula and the "+ delta" add a handful of roundings more.
     // Doubled, so that a borderline offset is always re-scored rather than dropped.
     double wmax = 0.0, dmax = 0.0;
-    for (int k = 0; k < 4; ++k) wmax = std::fmax(wmax, std::fabs(c->tables.weights[k]));
-    for (int r = 1; r <= c->tables.nranks; ++r) dmax = std::fmax(dmax, std::fabs(c->tables.delta_of_rank[r]));
+    for (int k = 0; k < 4; ++k) wmax = std::fmax(wmax, std::fabs(t.weights[k]));
+    for (int r = 1; r <= t.nranks; ++r) dmax = std::fmax(dmax, std::fabs(t.delta_of_rank[r]));
     const double u = 1.1102230246251565e-16;
     const double mag = (double)m * wmax + dmax;
     return 2.0 * 1.05 * ((double)m + 32.0) * u * mag;
 }
 
-psa::BoundParams bound_params(const psa_context* c, int m)
+psa::BoundParams bound_params(const psa::Tables& t, int m)
 {
-    const psa::Tables& t = c->tables;
     psa::BoundParams b;
     for (int i = 0; i < 4; ++i) {
         b.w[i] = t.weights[i];
         b.class_best[i] = t.class_best_delta[i];
         b.class_worst[i] = t.class_worst_delta[i];
     }
-    b.slack = filter_slack(c, m);
+    b.slack = filter_slack(t, m);
     b.m = m;
     b.is_max = t.is_max;
     return b;
@@ -684,8 +740,10 @@ psa::BoundParams bound_params(const psa_context* c, int m)
 
 // first/span describe the searched range when the kernel should also produce the score
 // bounds (single-chunk plans); span = 0 writes raw partial counts instead.
+// `s2`/`ts2` (optional): a second search of the same Seq2 in another mode, selected in the same pass.
 psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int base, int span_pad, int first,
-                        int span, bool inline_select, hipStream_t stream)
+                        int span, bool inline_select, hipStream_t stream, const TableSet& ts,
+                        const SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr)
 {
     psa::CountArgs a;
     a.s1 = c->d_s1;
@@ -698,15 +756,24 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.wave_chars = p.wave_chars;
     a.lds_slots = p.lds_slots;
     a.inline_select = inline_select ? 1 : 0;
-    a.global_best = &s.d_scal->global_best;
-    a.cand = s.d_cand;
-    a.cand_upper = s.d_cand_upper;
-    a.cand_count = &s.d_scal->cand_count;
+    a.nmodes = s2 ? 2 : 1;
     a.cap = kCandCap;
     a.first = first;
     a.lead = first - base;
     a.span = span;
-    a.bounds = bound_params(c, s.m);
+    a.sel[0].global_best = &s.d_scal->global_best;
+    a.sel[0].cand = s.d_cand;
+    a.sel[0].cand_upper = s.d_cand_upper;
+    a.sel[0].cand_count = &s.d_scal->cand_count;
+    a.sel[0].bounds = bound_params(*ts.t, s.m);
+    a.sel[1] = a.sel[0];
+    if (s2) {
+        a.sel[1].global_best = &s2->d_scal->global_best;
+        a.sel[1].cand = s2->d_cand;
+        a.sel[1].cand_upper = s2->d_cand_upper;
+        a.sel[1].cand_count = &s2->d_scal->cand_count;
+        a.sel[1].bounds = bound_params(*ts2->t, s.m);
+    }
     const dim3 grid(p.ntiles, p.nchunks);
     // dynamic LDS above 64 KB has to be granted per kernel; remember the largest grant
     static int granted16 = 0, granted8 = 0;
@@ -732,7 +799,8 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
 }
 
 // count (+ bounds) and candidate selection
-psa_status launch_filter_front(psa_context* c, SearchSlot& s, int first, int last, hipStream_t stream, bool profile)
+psa_status launch_filter_front(psa_context* c, SearchSlot& s, int first, int last, hipStream_t stream, bool profile,
+                               const TableSet& ts, SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr)
 {
     const int span = last - first;
     const int base = first & ~31;
@@ -743,9 +811,13 @@ psa_status launch_filter_front(psa_context* c, SearchSlot& s, int first, int las
     }
     const int span_pad = p.ntiles * psa::kTile;
     s.inline_select = p.nchunks == 1;
+    if (s2) {
+        if (!s.inline_select) { set_last_error("internal: two-mode selection needs a single-chunk plan"); return PSA_ERR_ARG; }
+        s2->inline_select = true;
+    }
     if (profile) PSA_HIP(hipEventRecord(c->ev[2], stream));
     if (s.inline_select) {
-        PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, true, stream));
+        PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, true, stream, ts, s2, ts2));
         if (profile) PSA_HIP(hipEventRecord(c->ev[3], stream));
         return PSA_OK;
     }
@@ -766,14 +838,14 @@ psa_status launch_filter_front(psa_context* c, SearchSlot& s, int first, int las
         PSA_TRY(dev_alloc(&s.d_block_best, (size_t)psa::kKeyBlocks));
         s.block_best_cap = psa::kKeyBlocks;
     }
-    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, false, stream));
+    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, false, stream, ts));
     if (profile) PSA_HIP(hipEventRecord(c->ev[3], stream));
 
     psa::KeyArgs k;
     k.partial = s.d_partial;
     k.upper = s.d_upper;
     k.block_best = s.d_block_best;
-    k.bounds = bound_params(c, s.m);
+    k.bounds = bound_params(*ts.t, s.m);
     k.nchunks = p.nchunks;
     k.span_pad = span_pad;
     k.span = span;
@@ -797,15 +869,16 @@ psa_status launch_filter_front(psa_context* c, SearchSlot& s, int first, int las
 }
 
 // exact re-score of the candidates + fold into the slot's tail
-psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hipStream_t stream)
+psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hipStream_t stream, const TableSet& ts,
+                              int grid = psa::kRescoreGrid)
 {
-    const psa::Tables& t = c->tables;
+    const psa::Tables& t = *ts.t;
     psa::RescoreArgs r;
     r.s1 = c->d_s1;
     r.s2 = s.s2bytes;
-    r.clsrank = c->d_clsrank;
-    r.sub = c->d_sub;
-    r.delta_of_rank = c->d_delta;
+    r.clsrank = ts.d_clsrank;
+    r.sub = ts.d_sub;
+    r.delta_of_rank = ts.d_delta;
     r.cand = s.d_cand;
     r.cand_upper = s.inline_select ? s.d_cand_upper : nullptr;
     r.global_best = &s.d_scal->global_best;
@@ -846,8 +919,8 @@ psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hi
                                     hipFuncAttributeMaxDynamicSharedMemorySize, psa::kRescorePadLds));
         granted = true;
     }
-    hipLaunchKernelGGL(psa::psa_rescore_kernel, dim3(psa::kRescoreGrid), dim3(psa::kRescoreThreads),
-                       psa::kRescorePadLds, stream, r);
+    hipLaunchKernelGGL(psa::psa_rescore_kernel, dim3(grid), dim3(psa::kRescoreThreads),
+                       c->rescore_pad ? psa::kRescorePadLds : 0, stream, r);
     PSA_HIP(hipGetLastError());
     return PSA_OK;
 }
@@ -953,6 +1026,7 @@ psa_status psa_create(int device, void* stream, psa_context** out)
             c->own_stream = true;
         }
         PSA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+        PSA_HIP(hipStreamCreateWithFlags(&c->twin, hipStreamNonBlocking));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_pair), sizeof(double) * psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_rank), psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_sub), psa::kRow * psa::kRow));
@@ -985,6 +1059,9 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     }();
     if (st != PSA_OK) { psa_destroy(c); return st; }
     if (const char* r = std::getenv("PSA_SEQ_R")) c->forced_r = std::atoi(r);
+    if (const char* r = std::getenv("PSA_BATCH_STREAMS")) c->batch_streams = std::atoi(r) >= 2 ? 2 : 1;
+    if (const char* r = std::getenv("PSA_RESCORE_GRID")) c->batch_rescore_grid = std::max(1, std::min(1024, std::atoi(r)));
+    if (const char* r = std::getenv("PSA_RESCORE_PAD")) c->rescore_pad = std::atoi(r) != 0;
     *out = c;
     return PSA_OK;
 }
@@ -995,6 +1072,7 @@ void psa_destroy(psa_context* c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux) (void)hipStreamSynchronize(c->aux);
+    if (c->twin) (void)hipStreamSynchronize(c->twin);
     (void)hipFree(c->d_raw);
     (void)hipFree(c->d_s1);
     (void)hipFree(c->d_pair);
@@ -1003,6 +1081,10 @@ void psa_destroy(psa_context* c)
     (void)hipFree(c->d_clsrank);
     (void)hipFree(c->d_delta);
     (void)hipFree(c->d_symbol_planes);
+    (void)hipFree(c->d_alt_rank);
+    (void)hipFree(c->d_alt_sub);
+    (void)hipFree(c->d_alt_delta);
+    (void)hipFree(c->d_alt_clsrank);
     (void)hipFree(c->d_bad);
     for (auto& s : c->slot) free_slot(s);
     (void)hipFree(c->d_batch_rows);
@@ -1018,6 +1100,7 @@ void psa_destroy(psa_context* c)
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->twin) (void)hipStreamDestroy(c->twin);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1030,6 +1113,7 @@ psa_status psa_set_weights(psa_context* c, const double weights[4], int is_max)
     if (!psa::build_tables(weights, is_max, &t, &err)) { set_last_error(err); return PSA_ERR_ARG; }
     PSA_TRY(ensure_device(c));
     c->tables = t;
+    c->have_alt = false;
     PSA_TRY(upload_tables(c));
     c->have_weights = true;
     return PSA_OK;
@@ -1093,10 +1177,10 @@ psa_status psa_search_async(psa_context* c, int first, int last)
         // enqueued but never waited for (or failed) can have left them dirty
         if (s.scal_dirty) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
         s.scal_dirty = true;
-        PSA_TRY(launch_filter_front(c, s, first, last, c->stream, c->profiling));
-        PSA_TRY(launch_filter_back(c, s, (long long)(last - first) * s.m, c->stream));
+        PSA_TRY(launch_filter_front(c, s, first, last, c->stream, c->profiling, primary_tables(c)));
+        PSA_TRY(launch_filter_back(c, s, (long long)(last - first) * s.m, c->stream, primary_tables(c)));
     } else {
-        PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream));
+        PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream, primary_tables(c)));
     }
     PSA_HIP(hipMemcpyAsync(&c->h_tails[0], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
     if (c->profiling) {
@@ -1126,7 +1210,7 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
         // score every offset in reference order instead
         c->fallbacks += 1;
         c->seq += 1;
-        PSA_TRY(launch_sequential(c, c->slot[0], c->pending_first, c->pending_last, nullptr, nullptr, c->stream));
+        PSA_TRY(launch_sequential(c, c->slot[0], c->pending_first, c->pending_last, nullptr, nullptr, c->stream, primary_tables(c)));
         PSA_HIP(hipMemcpyAsync(&c->h_tails[0], c->slot[0].d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
         PSA_HIP(hipStreamSynchronize(c->stream));
         c->timing_valid = false;
@@ -1150,22 +1234,29 @@ psa_status psa_search(psa_context* c, int first, int last, psa_result* out)
 }
 
 // nq queries of m characters each, `stride` bytes apart in one device buffer, against the
-// context's Seq1 and weights; results[q] in host memory.  Query q+1's count kernel runs on
-// the main stream while query q's re-score and read-back run on the context's second stream.
-psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq, int m, size_t stride,
-                                   int first, int last, psa_result* results)
+// context's Seq1 and weights; results in host memory.  results1 != NULL asks for the opposite
+// mode as well (MIN next to MAX): the class counts of an offset do not depend on the mode, so
+// both searches of a query share one count pass and differ only in bounds, candidates and
+// re-score.  Count kernels of consecutive queries alternate between two streams; the re-score
+// and read-back of every query run on a third.
+static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int m, size_t stride,
+                             int first, int last, psa_result* results0, psa_result* results1)
 {
-    if (!c || !d_queries || !results || nq < 1 || stride < (size_t)m) {
+    if (!c || !d_queries || !results0 || nq < 1 || stride < (size_t)m) {
         set_last_error("psa_search_batch: bad arguments");
         return PSA_ERR_ARG;
     }
     PSA_TRY(check_ready(c, m, first, last));
     PSA_TRY(ensure_device(c));
-    PSA_TRY(ensure_tails(c, nq));
+    const int nmodes = results1 ? 2 : 1;
+    if (nmodes == 2) PSA_TRY(ensure_alt_tables(c));
+    const TableSet tables[2] = {primary_tables(c), alternate_tables(c)};
+    psa_result* const results[2] = {results0, results1};
+    PSA_TRY(ensure_tails(c, nq * nmodes));
     const unsigned char* base = static_cast<const unsigned char*>(d_queries);
     const bool filter = use_filter(c, first, last, m);
     const long long pairs = (long long)(last - first) * m;
-    const int seq0 = c->seq + 1;       // query q carries sequence number seq0 + q
+    const int seq0 = c->seq + 1;
     // all queries encoded by one launch: [nq][ostride] codes as u32 rows and as bytes
     const int ostride = (m + kSeq2Slack + 63) & ~63;
     if ((size_t)nq * ostride > c->batch_cap) {
@@ -1177,73 +1268,112 @@ psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq
     hipLaunchKernelGGL(psa::psa_encode_batch_kernel, dim3((ostride + 255) / 256, nq), dim3(256), 0, c->stream,
                        base, nq, m, stride, c->d_batch_rows, c->d_batch_bytes, ostride, c->d_bad);
     PSA_HIP(hipGetLastError());
-    // single-chunk filter plans keep all per-query state in pools: nothing is reused inside the
-    // batch and the main stream runs count kernels back to back
+    // single-chunk filter plans keep all per-query state in pools (entry mode*nq + q): nothing is
+    // reused inside the batch and the count kernels never wait for the re-score stream
     FilterPlan plan;
     const bool pooled = filter && plan_filter(first, last, m, &plan) && plan.nchunks == 1;
     if (pooled) {
-        PSA_TRY(ensure_pool(c, nq));
-        PSA_HIP(hipMemsetAsync(c->d_pool_scal, 0, sizeof(Scalars) * (size_t)nq, c->stream));
+        PSA_TRY(ensure_pool(c, nq * nmodes));
+        PSA_HIP(hipMemsetAsync(c->d_pool_scal, 0, sizeof(Scalars) * (size_t)nq * nmodes, c->stream));
     }
     for (auto& s : c->slot) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
-    // the aux stream must see everything already enqueued on the main stream (Seq1 planes, tables, codes)
+    // the other streams must see everything already enqueued on the main stream (Seq1 codes, tables, query codes)
     hipEvent_t& gate = c->slot[0].front_done;
     PSA_HIP(hipEventRecord(gate, c->stream));
     PSA_HIP(hipStreamWaitEvent(c->aux, gate, 0));
-    for (int q = 0; q < nq; ++q) {
-        SearchSlot view = c->slot[q % kSlots];     // pointers only; pooled queries override the small buffers
-        SearchSlot& s = pooled ? view : c->slot[q % kSlots];
-        if (pooled) {
-            view.d_scal = c->d_pool_scal + q;
-            view.d_cand = c->d_pool_cand + (size_t)q * kCandCap;
-            view.d_cand_upper = c->d_pool_cand_upper + (size_t)q * kCandCap;
-            view.d_rec = c->d_pool_rec + (size_t)q * kCandCap;
-            view.d_tail = c->d_pool_tail + q;
-            view.front_done = c->pool_events[q];
-        } else if (q >= kSlots) {
-            PSA_HIP(hipStreamWaitEvent(c->stream, s.back_done, 0));   // slot free again
+    // pooled queries share nothing, so their count kernels alternate between two streams: the next
+    // kernel's workgroups fill the CUs the previous one leaves idle (245 tiles on 256 CUs, launch gaps)
+    const bool twin = pooled && c->batch_streams == 2;
+    if (twin) PSA_HIP(hipStreamWaitEvent(c->twin, gate, 0));
+    // sequence number echoed by the tail of (mode, q)
+    auto seq_of = [&](int mode, int q) { return pooled ? seq0 + q : seq0 + mode * nq + q; };
+    auto pool_view = [&](int mode, int q) {
+        SearchSlot v = c->slot[0];            // pointers only; the pool overrides the per-search buffers
+        const size_t e = (size_t)mode * nq + q;
+        v.d_scal = c->d_pool_scal + e;
+        v.d_cand = c->d_pool_cand + e * kCandCap;
+        v.d_cand_upper = c->d_pool_cand_upper + e * kCandCap;
+        v.d_rec = c->d_pool_rec + e * kCandCap;
+        v.d_tail = c->d_pool_tail + e;
+        v.front_done = c->pool_events[e];
+        v.m = m;
+        v.s2rows = c->d_batch_rows + (size_t)q * ostride;
+        v.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
+        return v;
+    };
+    if (pooled) {
+        for (int q = 0; q < nq; ++q) {
+            hipStream_t front = twin && (q & 1) ? c->twin : c->stream;
+            SearchSlot s0 = pool_view(0, q);
+            SearchSlot s1 = pool_view(nmodes - 1, q);
+            c->seq = seq0 + q;
+            PSA_TRY(launch_filter_front(c, s0, first, last, front, false, tables[0], nmodes == 2 ? &s1 : nullptr, &tables[1]));
+            PSA_HIP(hipEventRecord(s0.front_done, front));
+            PSA_HIP(hipStreamWaitEvent(c->aux, s0.front_done, 0));
+            PSA_TRY(launch_filter_back(c, s0, pairs, c->aux, tables[0], c->batch_rescore_grid));
+            PSA_HIP(hipMemcpyAsync(&c->h_tails[q], s0.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->aux));
+            if (nmodes == 2) {
+                PSA_TRY(launch_filter_back(c, s1, pairs, c->aux, tables[1], c->batch_rescore_grid));
+                PSA_HIP(hipMemcpyAsync(&c->h_tails[nq + q], s1.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->aux));
+            }
         }
-        s.m = m;
-        s.s2rows = c->d_batch_rows + (size_t)q * ostride;
-        s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
-        c->seq = seq0 + q;
-        if (filter) {
-            PSA_TRY(launch_filter_front(c, s, first, last, c->stream, false));
-            PSA_HIP(hipEventRecord(s.front_done, c->stream));
-            PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
-            PSA_TRY(launch_filter_back(c, s, pairs, c->aux));
-        } else {
-            PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream));
-            PSA_HIP(hipEventRecord(s.front_done, c->stream));
-            PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
-        }
-        PSA_HIP(hipMemcpyAsync(&c->h_tails[q], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->aux));
-        if (!pooled) PSA_HIP(hipEventRecord(s.back_done, c->aux));
+    } else {
+        for (int mode = 0; mode < nmodes; ++mode)
+            for (int q = 0; q < nq; ++q) {
+                const int k = mode * nq + q;
+                SearchSlot& s = c->slot[k % kSlots];
+                if (k >= kSlots) PSA_HIP(hipStreamWaitEvent(c->stream, s.back_done, 0));   // slot free again
+                s.m = m;
+                s.s2rows = c->d_batch_rows + (size_t)q * ostride;
+                s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
+                c->seq = seq_of(mode, q);
+                if (filter) {
+                    PSA_TRY(launch_filter_front(c, s, first, last, c->stream, false, tables[mode]));
+                    PSA_HIP(hipEventRecord(s.front_done, c->stream));
+                    PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
+                    PSA_TRY(launch_filter_back(c, s, pairs, c->aux, tables[mode]));
+                } else {
+                    PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream, tables[mode]));
+                    PSA_HIP(hipEventRecord(s.front_done, c->stream));
+                    PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
+                }
+                PSA_HIP(hipMemcpyAsync(&c->h_tails[k], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->aux));
+                PSA_HIP(hipEventRecord(s.back_done, c->aux));
+            }
     }
     PSA_HIP(hipStreamSynchronize(c->aux));
+    if (twin) PSA_HIP(hipStreamSynchronize(c->twin));
     PSA_HIP(hipStreamSynchronize(c->stream));
     int bad = 0;
-    for (int q = 0; q < nq; ++q) bad |= c->h_tails[q].bad;
+    for (int k = 0; k < nq * nmodes; ++k) bad |= c->h_tails[k].bad;
     *c->h_bad = bad;
     PSA_TRY(report_bad(c));
-    for (int q = 0; q < nq; ++q) {
-        if (filter && (c->h_tails[q].overflow || c->h_tails[q].seq != seq0 + q)) {
-            SearchSlot& s = c->slot[0];
-            c->fallbacks += 1;
-            c->seq += 1;
-            for (auto& sl : c->slot) sl.scal_dirty = true;
-            s.m = m;
-            s.s2rows = c->d_batch_rows + (size_t)q * ostride;
-            s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
-            PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream));
-            PSA_HIP(hipMemcpyAsync(&c->h_tails[q], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
-            PSA_HIP(hipStreamSynchronize(c->stream));
+    for (int mode = 0; mode < nmodes; ++mode)
+        for (int q = 0; q < nq; ++q) {
+            const int k = mode * nq + q;
+            if (filter && (c->h_tails[k].overflow || c->h_tails[k].seq != seq_of(mode, q))) {
+                SearchSlot& s = c->slot[0];
+                c->fallbacks += 1;
+                c->seq += 1;
+                for (auto& sl : c->slot) sl.scal_dirty = true;
+                s.m = m;
+                s.s2rows = c->d_batch_rows + (size_t)q * ostride;
+                s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
+                PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream, tables[mode]));
+                PSA_HIP(hipMemcpyAsync(&c->h_tails[k], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
+                PSA_HIP(hipStreamSynchronize(c->stream));
+            }
+            results[mode][q] = c->h_tails[k].result;
+            results[mode][q].shard = q;
         }
-        results[q] = c->h_tails[q].result;
-        results[q].shard = q;
-    }
     for (auto& s : c->slot) s.m = -1;      // the single-search Seq2 is gone
     return PSA_OK;
+}
+
+psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq, int m, size_t stride,
+                                   int first, int last, psa_result* results)
+{
+    return batch_impl(c, d_queries, nq, m, stride, first, last, results, nullptr);
 }
 
 psa_status psa_search_batch(psa_context* c, const char* queries, int nq, int m, size_t stride,
@@ -1253,7 +1383,26 @@ psa_status psa_search_batch(psa_context* c, const char* queries, int nq, int m, 
     PSA_TRY(ensure_device(c));
     PSA_TRY(stage_host(c, queries, (size_t)(nq - 1) * stride + (size_t)m));
     PSA_HIP(hipStreamSynchronize(c->stream));
-    return psa_search_batch_device(c, c->d_raw, nq, m, stride, first, last, results);
+    return batch_impl(c, c->d_raw, nq, m, stride, first, last, results, nullptr);
+}
+
+psa_status psa_search_batch_minmax_device(psa_context* c, const void* d_queries, int nq, int m, size_t stride,
+                                          int first, int last, psa_result* results_max, psa_result* results_min)
+{
+    if (!c || !results_max || !results_min) { set_last_error("psa_search_batch_minmax: NULL argument"); return PSA_ERR_ARG; }
+    if (!c->have_weights) { set_last_error("weights, seq1 and seq2 must be set before a search"); return PSA_ERR_STATE; }
+    const bool mx = c->tables.is_max != 0;      // results0 is the context's own mode
+    return batch_impl(c, d_queries, nq, m, stride, first, last, mx ? results_max : results_min, mx ? results_min : results_max);
+}
+
+psa_status psa_search_batch_minmax(psa_context* c, const char* queries, int nq, int m, size_t stride,
+                                   int first, int last, psa_result* results_max, psa_result* results_min)
+{
+    if (!c || !queries || nq < 1 || stride < (size_t)m) { set_last_error("psa_search_batch_minmax: bad arguments"); return PSA_ERR_ARG; }
+    PSA_TRY(ensure_device(c));
+    PSA_TRY(stage_host(c, queries, (size_t)(nq - 1) * stride + (size_t)m));
+    PSA_HIP(hipStreamSynchronize(c->stream));
+    return psa_search_batch_minmax_device(c, c->d_raw, nq, m, stride, first, last, results_max, results_min);
 }
 
 psa_status psa_scores(psa_context* c, int first, int last, double* scores, int32_t* char_offsets, int32_t* chs)
@@ -1272,7 +1421,7 @@ psa_status psa_scores(psa_context* c, int first, int last, double* scores, int32
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_prank), (size_t)span));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_ci), sizeof(int) * (size_t)span));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&d_ch), sizeof(int) * (size_t)span));
-        PSA_TRY(launch_sequential(c, s, first, last, d_score, d_prank, c->stream));
+        PSA_TRY(launch_sequential(c, s, first, last, d_score, d_prank, c->stream, primary_tables(c)));
         hipLaunchKernelGGL(psa::psa_first_index_kernel, dim3((span + 255) / 256), dim3(256), 0, c->stream,
                            c->d_s1, s.s2rows, c->d_rank, c->d_sub, d_prank, first, last, s.m, d_ci, d_ch);
         PSA_HIP(hipGetLastError());
@@ -1311,7 +1460,7 @@ psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_sta
         PSA_TRY(dev_alloc(&s.d_partial, need));
         s.partial_cap = need;
     }
-    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, false, c->stream));
+    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, false, c->stream, primary_tables(c)));
     std::vector<unsigned long long> host(need);
     PSA_HIP(hipMemcpyAsync(host.data(), s.d_partial, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1328,6 +1477,14 @@ psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_sta
     }
     return PSA_OK;
 }
+
+#ifdef PSA_PHASE_TIMING
+// debug build only (tools/phase_timing.py): the count kernel's phase timestamps
+int psa_debug_phase_ts(unsigned long long* out /* [1024][8] */)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psa::g_phase_ts), sizeof(unsigned long long) * 1024 * 8);
+}
+#endif
 
 // Diagnostic: the filter engine's exact re-score of arbitrary offsets
 // (find_best_mutant_offset's return value, cpu_funcs.c:299) without the filter.
@@ -1350,7 +1507,7 @@ psa_status psa_debug_rescore(psa_context* c, const int32_t* offsets, int count, 
     s.inline_select = false;
     PSA_HIP(hipMemcpyAsync(s.d_scal, &sc, sizeof sc, hipMemcpyHostToDevice, c->stream));
     PSA_HIP(hipMemcpyAsync(s.d_cand, offsets, sizeof(int) * (size_t)count, hipMemcpyHostToDevice, c->stream));
-    PSA_TRY(launch_filter_back(c, s, 0, c->stream));
+    PSA_TRY(launch_filter_back(c, s, 0, c->stream, primary_tables(c)));
     std::vector<psa::CandRec> host((size_t)count);
     PSA_HIP(hipMemcpyAsync(host.data(), s.d_rec, sizeof(psa::CandRec) * (size_t)count, hipMemcpyDeviceToHost, c->stream));
     PSA_HIP(hipMemcpyAsync(c->h_bad, c->d_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));

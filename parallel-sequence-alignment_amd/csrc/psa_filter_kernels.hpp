@@ -297,18 +297,31 @@ struct CountArgs {
     int wave_chars;   // chars per wave   (multiple of kUnroll, <= kMaxWaveChars)
     int lds_slots;    // slots per staged row
     // single-chunk searches finish here: score bounds per offset, running best pessimistic
-    // bound (atomic max), candidates = offsets whose optimistic bound reaches it
+    // bound (atomic max), candidates = offsets whose optimistic bound reaches it.  The counts do
+    // not depend on the search mode, so one pass can select for several modes (MAX and MIN of the
+    // same weights): one CountSelect each.
     int inline_select;                // 0: write `partial`, psa_keys_kernel + psa_select_kernel follow
-    unsigned long long* global_best;  // ordered-u64, 0 before the search
-    int*                cand;         // [cap] absolute offsets
-    double*             cand_upper;   // [cap] their optimistic bounds (re-checked against the final best)
-    int*                cand_count;
+    int nmodes;                       // 1 or 2
     int cap;
     int first;                        // first offset of the searched range
     int lead;                         // offsets of tile 0 in front of the range (first - base)
     int span;
-    BoundParams bounds;
+    struct CountSelect {
+        unsigned long long* global_best;  // ordered-u64, 0 before the search
+        int*                cand;         // [cap] absolute offsets
+        double*             cand_upper;   // [cap] their optimistic bounds (re-checked against the final best)
+        int*                cand_count;
+        BoundParams         bounds;
+    } sel[2];
 };
+
+#ifdef PSA_PHASE_TIMING
+// debug build only: 100 MHz timestamps of the count kernel's phases, [block][phase]
+__device__ unsigned long long g_phase_ts[1024][8];
+#define PSA_PHASE(k) do { if (tid == 0 && blockIdx.x < 1024) g_phase_ts[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define PSA_PHASE(k) do { } while (0)
+#endif
 
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
@@ -327,25 +340,36 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     // (symbol_planes: bit b = the relation of that Seq1 symbol to b) and transposes the two 32x32
     // bit matrices in registers — 14 KB of codes read per workgroup instead of 100 KB of planes.
     __shared__ unsigned s_planes[64];
-    if (tid < 64) s_planes[tid] = a.symbol_planes[tid];
-    __syncthreads();
-    for (int slot = tid; slot < a.lds_slots; slot += WAVES * 64) {
-        const uint4* src = reinterpret_cast<const uint4*>(a.s1 + ((size_t)(slot0 + slot) << 5));
-        const uint4 c0 = src[0], c1 = src[1];
-        const unsigned w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-        unsigned lo[32], hi[32];
+    PSA_PHASE(0);
+    {
+        // the lower half of the workgroup transposes the lo planes, the upper half the hi planes;
+        // a thread's first 32 codes are fetched together with the symbol table (one memory latency)
+        constexpr int kHalf = WAVES * 32;
+        static_assert(kHalf % 64 == 0, "the split must fall on a wave boundary");
+        const int hi_half = tid >= kHalf ? 1 : 0;
+        int slot = tid - kHalf * hi_half;
+        const uint4* src = reinterpret_cast<const uint4*>(a.s1 + ((size_t)slot0 << 5));
+        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+        if (slot < a.lds_slots) { c0 = src[2 * slot]; c1 = src[2 * slot + 1]; }
+        if (tid < 64) s_planes[tid] = a.symbol_planes[tid];
+        __syncthreads();
+        const unsigned* tab = s_planes + 32 * hi_half;
+        unsigned* dst = reinterpret_cast<unsigned*>(lds) + hi_half;
+        while (slot < a.lds_slots) {
+            const unsigned w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const int next = slot + kHalf;
+            if (next < a.lds_slots) { c0 = src[2 * next]; c1 = src[2 * next + 1]; }
+            unsigned v[32];
 #pragma unroll
-        for (int t = 0; t < 32; ++t) {
-            const unsigned code = (w[t >> 2] >> (8 * (t & 3))) & 0xffu;
-            lo[t] = s_planes[code];
-            hi[t] = s_planes[32 + code];
+            for (int t = 0; t < 32; ++t) v[t] = tab[(w[t >> 2] >> (8 * (t & 3))) & 0xffu];
+            transpose32(v);
+#pragma unroll
+            for (int b = 0; b < kMaskRows; ++b) dst[(b * kRowSlots + slot) * 2] = v[b];
+            slot = next;
         }
-        transpose32(lo);
-        transpose32(hi);
-#pragma unroll
-        for (int b = 0; b < kMaskRows; ++b) lds[b * kRowSlots + slot] = make_uint2(lo[b], hi[b]);
     }
     __syncthreads();
+    PSA_PHASE(1);
 
     SlicedCounter cnt[2][kCounters];     // [word][n_lo, n_hi, n_both]
 #pragma unroll
@@ -382,7 +406,9 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
 
     // ---- epilogue: sum the WAVES partial counters (bit-sliced ripple adds through LDS),
     // then expand the merged planes to integers and store them.
+    PSA_PHASE(2);
     __syncthreads();                                 // rows no longer needed: LDS is scratch now
+    PSA_PHASE(3);
     unsigned* scratch = reinterpret_cast<unsigned*>(lds);
     // merged[word][counter][plane]: grows by one plane per round
     unsigned merged[2][kCounters][kMergedPlanes];
@@ -436,6 +462,7 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     }
 
     // wave 0 publishes the merged planes: layout [counter][plane][word(128)]
+    PSA_PHASE(4);
     unsigned* pub = scratch;
     if (wave == 0) {
 #pragma unroll
@@ -473,46 +500,51 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
         return;
     }
     // one chunk: the counts are final
-    double up[kPer];
-    double pess = -INFINITY;
-#pragma unroll
-    for (int e = 0; e < kPer; ++e) {
-        const int o = (int)blockIdx.x * kTile + o_local + e - a.lead;      // relative to the range's first offset
-        up[e] = -INFINITY;
-        if (o >= 0 && o < a.span) {
-            double pe;
-            offset_bounds(a.bounds, (int)n[0][e], (int)n[1][e], (int)n[2][e], up[e], pe);
-            pess = fmax(pess, pe);
-        }
-    }
-    unsigned long long key = order_key(pess);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long other = __shfl_xor(key, d, 64);
-        key = other > key ? other : key;
-    }
-    __syncthreads();                                  // everyone is done reading `pub`
+    PSA_PHASE(5);
     unsigned long long* s_best = reinterpret_cast<unsigned long long*>(scratch);
-    if (lane == 0) s_best[wave] = key;
-    __syncthreads();
-    if (tid == 0) {
-        for (int w = 1; w < WAVES; ++w) key = s_best[w] > key ? s_best[w] : key;
-        // running best over the tiles finished so far: a lower bound of the final best, so selecting
-        // against it keeps a superset of the true candidates (the re-score kernel re-checks)
-        const unsigned long long old = atomicMax(a.global_best, key);
-        s_best[WAVES] = old > key ? old : key;
-    }
-    __syncthreads();
-    const double need = key_order(s_best[WAVES]);
+    for (int mode = 0; mode < a.nmodes; ++mode) {
+        const CountArgs::CountSelect& sel = a.sel[mode];
+        __syncthreads();                              // everyone is done reading `pub` / the previous mode's s_best
+        double up[kPer];
+        double pess = -INFINITY;
 #pragma unroll
-    for (int e = 0; e < kPer; ++e)
-        if (up[e] >= need) {
-            const int slot = atomicAdd(a.cand_count, 1);
-            if (slot < a.cap) {
-                a.cand[slot] = a.first + (int)blockIdx.x * kTile + o_local + e - a.lead;
-                a.cand_upper[slot] = up[e];
+        for (int e = 0; e < kPer; ++e) {
+            const int o = (int)blockIdx.x * kTile + o_local + e - a.lead;      // relative to the range's first offset
+            up[e] = -INFINITY;
+            if (o >= 0 && o < a.span) {
+                double pe;
+                offset_bounds(sel.bounds, (int)n[0][e], (int)n[1][e], (int)n[2][e], up[e], pe);
+                pess = fmax(pess, pe);
             }
         }
+        unsigned long long key = order_key(pess);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long other = __shfl_xor(key, d, 64);
+            key = other > key ? other : key;
+        }
+        if (lane == 0) s_best[wave] = key;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < WAVES; ++w) key = s_best[w] > key ? s_best[w] : key;
+            // running best over the tiles finished so far: a lower bound of the final best, so selecting
+            // against it keeps a superset of the true candidates (the re-score kernel re-checks)
+            const unsigned long long old = atomicMax(sel.global_best, key);
+            s_best[WAVES] = old > key ? old : key;
+        }
+        __syncthreads();
+        const double need = key_order(s_best[WAVES]);
+#pragma unroll
+        for (int e = 0; e < kPer; ++e)
+            if (up[e] >= need) {
+                const int slot = atomicAdd(sel.cand_count, 1);
+                if (slot < a.cap) {
+                    sel.cand[slot] = a.first + (int)blockIdx.x * kTile + o_local + e - a.lead;
+                    sel.cand_upper[slot] = up[e];
+                }
+            }
+    }
+    PSA_PHASE(6);
 }
 
 // ---- keys (searches with several char chunks): counts -> score interval per offset

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = (
     "psa_set_seq1", "psa_set_seq2", "psa_set_seq1_device", "psa_set_seq2_device",
     "psa_set_engine", "psa_search", "psa_search_async", "psa_search_wait", "psa_scores",
     "psa_search_batch", "psa_search_batch_device",
+    "psa_search_batch_minmax", "psa_search_batch_minmax_device",
     "psa_debug_counts", "psa_fallback_count", "psa_debug_rescore",
     "psa_fold", "psa_shard_range", "psa_build_tables",
     "psa_set_profiling", "psa_last_timing", "psa_profile_totals",
@@ -83,6 +84,8 @@ def _load() -> C.CDLL:
     lib.psa_scores.argtypes = [vp, i, i, vp, vp, vp]
     lib.psa_search_batch.argtypes = [vp, C.c_char_p, i, i, C.c_size_t, i, i, C.POINTER(Result)]
     lib.psa_search_batch_device.argtypes = [vp, vp, i, i, C.c_size_t, i, i, C.POINTER(Result)]
+    lib.psa_search_batch_minmax.argtypes = [vp, C.c_char_p, i, i, C.c_size_t, i, i, C.POINTER(Result), C.POINTER(Result)]
+    lib.psa_search_batch_minmax_device.argtypes = [vp, vp, i, i, C.c_size_t, i, i, C.POINTER(Result), C.POINTER(Result)]
     lib.psa_debug_counts.argtypes = [vp, i, i, vp, vp, vp]
     lib.psa_fallback_count.argtypes = [vp]
     lib.psa_debug_rescore.argtypes = [vp, vp, i, vp]
@@ -250,6 +253,30 @@ class Context:
         _check(lib.psa_search_batch_device(self._h, C.c_void_p(ptr), nq, m, stride, first, last, out))
         self.m = None
         return list(out)
+
+    def search_batch_minmax(self, queries: Sequence[bytes], first: Optional[int] = None, last: Optional[int] = None):
+        """Equal-length host queries -> (MAX results, MIN results) from one shared count pass."""
+        m = len(queries[0])
+        if any(len(q) != m for q in queries):
+            raise ValueError("all queries of a batch must have the same length")
+        first = 0 if first is None else first
+        last = self.n - m + 1 if last is None else last
+        hi = (Result * len(queries))()
+        lo = (Result * len(queries))()
+        _check(lib.psa_search_batch_minmax(self._h, b"".join(queries), len(queries), m, m, first, last, hi, lo))
+        self.m = None
+        return list(hi), list(lo)
+
+    def search_batch_minmax_device(self, ptr: int, nq: int, m: int, stride: int,
+                                   first: Optional[int] = None, last: Optional[int] = None):
+        """Queries already in HBM (psa_search_batch_minmax_device)."""
+        first = 0 if first is None else first
+        last = self.n - m + 1 if last is None else last
+        hi = (Result * nq)()
+        lo = (Result * nq)()
+        _check(lib.psa_search_batch_minmax_device(self._h, C.c_void_p(ptr), nq, m, stride, first, last, hi, lo))
+        self.m = None
+        return list(hi), list(lo)
 
     def scores(self, first: Optional[int] = None, last: Optional[int] = None):
         first = 0 if first is None else first

@@ -449,6 +449,82 @@ def test_batch_full_size_device_queries(psa):
                (gold["offset"], gold["char_offset"], gold["ch"], gold["score"])
 
 
+def test_batch_minmax_matches_oracle(psa, oracle):
+    """psa_search_batch_minmax: MAX and MIN of every query from one shared count pass == the oracle's two
+    searches; filter (pooled and multi-chunk) and sequential engines, contexts in either mode, a
+    sub-range, and a tie-heavy query that falls back in one or both modes."""
+    s1 = psa.generate_sequence(181, 40000)
+    queries = [psa.generate_sequence(1900 + q, 300) for q in range(5)]
+    queries[2] = s1[4321:4621]
+    for engine in (psa.ENGINE_FILTER, psa.ENGINE_SEQUENTIAL):
+        for ctx_mode in (True, False):
+            with psa.Context(0) as c:
+                c.set_engine(engine)
+                c.set_weights(W_README, ctx_mode)
+                c.set_seq1(s1)
+                hi, lo = c.search_batch_minmax(queries)
+                for q, a, b in zip(queries, hi, lo):
+                    assert_same(a, oracle.search(s1, q, W_README, True, threads=8))
+                    assert_same(b, oracle.search(s1, q, W_README, False, threads=8))
+                hi, lo = c.search_batch_minmax(queries[:2], 50, 30001)
+                for q, a, b in zip(queries, hi, lo):
+                    assert_same(a, oracle.search(s1, q, W_README, True, 50, 30001, threads=8))
+                    assert_same(b, oracle.search(s1, q, W_README, False, 50, 30001, threads=8))
+                # the context's own mode is untouched
+                c.set_seq2(queries[0])
+                assert_same(c.search(), oracle.search(s1, queries[0], W_README, ctx_mode, threads=8))
+    # several char chunks (no pooled state): the two modes run one after the other
+    s1 = psa.generate_sequence(191, 60000)
+    qs = [psa.generate_sequence(192, 20011), psa.generate_sequence(193, 20011)]
+    with psa.Context(0) as c:
+        c.set_engine(psa.ENGINE_FILTER)
+        c.set_weights(W_README, True)
+        c.set_seq1(s1)
+        hi, lo = c.search_batch_minmax(qs)
+        for q, a, b in zip(qs, hi, lo):
+            assert_same(a, oracle.search(s1, q, W_README, True, threads=8))
+            assert_same(b, oracle.search(s1, q, W_README, False, threads=8))
+    # ties: homopolymer queries overflow the candidate list
+    with psa.Context(0) as c:
+        c.set_engine(psa.ENGINE_FILTER)
+        c.set_weights([1, 1, 1, 1], False)
+        s1 = b"A" * 9000
+        qs = [b"A" * 200, psa.generate_sequence(6, 200)]
+        c.set_seq1(s1)
+        hi, lo = c.search_batch_minmax(qs)
+        for q, a, b in zip(qs, hi, lo):
+            assert_same(a, oracle.search(s1, q, [1, 1, 1, 1], True, threads=8))
+            assert_same(b, oracle.search(s1, q, [1, 1, 1, 1], False, threads=8))
+        assert c.fallback_count() >= 1
+
+
+def test_batch_minmax_full_size(psa):
+    """1M x 10k, queries in HBM: the shared-count MIN+MAX batch == one MAX batch and one MIN batch; query 0
+    reproduces both committed goldens."""
+    import torch
+    n, m, nq = 1_000_000, 10_000, 4
+    s1 = psa.generate_sequence_np(1002, n)
+    qs = np.stack([psa.generate_sequence_np(2002 + q, m) for q in range(nq)])
+    t1 = torch.from_numpy(s1).cuda()
+    tq = torch.from_numpy(qs).cuda()
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch, r.pairs, r.shard)
+    with psa.Context(0) as c:
+        c.set_weights(W_README, True)
+        c.set_seq1_device(t1.data_ptr(), n)
+        hi, lo = c.search_batch_minmax_device(tq.data_ptr(), nq, m, m)
+        want_hi = c.search_batch_device(tq.data_ptr(), nq, m, m)
+        c.set_weights(W_README, False)
+        want_lo = c.search_batch_device(tq.data_ptr(), nq, m, m)
+        hi2, lo2 = c.search_batch_minmax_device(tq.data_ptr(), nq, m, m)      # from a MIN context
+        assert [key(r) for r in hi] == [key(r) for r in want_hi] == [key(r) for r in hi2]
+        assert [key(r) for r in lo] == [key(r) for r in want_lo] == [key(r) for r in lo2]
+        assert c.fallback_count() == 0
+        gold = {c_["name"]: c_ for c_ in json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))["cases"]}
+        for res, name in ((hi[0], "c3_max"), (lo[0], "c3_min")):
+            g = gold[name]
+            assert (res.offset, res.char_offset, chr(res.ch), "%.17g" % res.score) == (g["offset"], g["char_offset"], g["ch"], g["score"])
+
+
 def test_drop_in_program(psa, tmp_path):
     """host/psa_main: ./input.txt -> ./output.txt byte-for-byte, the reference's stdout lines and exit codes
     (main.c:13-56, cpu_funcs.c:25-121)."""

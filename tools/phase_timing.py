@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Phase timestamps of psa_count_kernel (debug build with -DPSA_PHASE_TIMING, libpsa_phase.so).
+
+  PSA_AMD_LIB=.../libpsa_phase.so python tools/phase_timing.py [n] [m]
+prints, over all workgroups, the mean/min/max duration of each phase in microseconds."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "parallel-sequence-alignment_amd"))
+import psa_amd  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+m = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
+ctx = psa_amd.Context()
+ctx.set_weights([1.5, 2.6, 0.3, 0.2], True)
+ctx.set_seq1(psa_amd.generate_sequence(1002, n))
+ctx.set_seq2(psa_amd.generate_sequence(2002, m))
+for _ in range(3):
+    r = ctx.search(0, n - m + 1)
+lib = psa_amd._lib if hasattr(psa_amd, "_lib") else psa_amd.lib
+buf = (C.c_ulonglong * (1024 * 8))()
+lib.psa_debug_phase_ts.restype = C.c_int
+assert lib.psa_debug_phase_ts(buf) == 0
+ts = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
+nt = (n - m + 1 + 4095) // 4096 + 1
+ts = ts[:nt]
+ts = ts[ts[:, 0] > 0]
+t0 = ts[:, 0].min()
+names = ["build planes", "main loop (wave 0)", "barrier wait", "merge tree", "publish+expand", "bounds+select"]
+print(f"{len(ts)} workgroups; start spread {(ts[:,0].max()-t0)/100:.2f} us; last end {(ts[:,6].max()-t0)/100:.2f} us")
+for k, name in enumerate(names):
+    d = (ts[:, k + 1] - ts[:, k]) / 100.0
+    print(f"{name:22s} mean {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
+print("result", r)
