@@ -359,7 +359,7 @@ struct SearchSlot {
     int*                d_cand = nullptr;
     double*             d_cand_upper = nullptr;
     psa::CandRec*       d_rec = nullptr;
-    psa::SearchTail*    d_tail = nullptr;
+    psa::SearchTail*    d_tail = nullptr;      // not owned: the search's entry of the context's host-mapped tails
     hipEvent_t          front_done = nullptr;  // count + select enqueued
     hipEvent_t          back_done = nullptr;   // re-score + read-back enqueued
 };
@@ -399,7 +399,10 @@ struct psa_context {
     unsigned char* d_alt_clsrank = nullptr;
     int*           d_bad = nullptr;
     int*           h_bad = nullptr;       // pinned
-    psa::SearchTail* h_tails = nullptr;   int tails_cap = 0;     // pinned, one per query of a batch (>= 1)
+    // pinned, host-coherent, one per search of a batch (>= 1).  The kernels write the 48-byte tail
+    // straight into it (hd_tails = the device-side alias): no D2H copy command per search.
+    psa::SearchTail* h_tails = nullptr;   int tails_cap = 0;
+    psa::SearchTail* hd_tails = nullptr;
     unsigned int*  d_batch_rows = nullptr;   // codes of all queries of a batch
     unsigned char* d_batch_bytes = nullptr;  size_t batch_cap = 0;
     // per-query search state of a batch (no buffer is reused inside a batch, so the main
@@ -408,7 +411,6 @@ struct psa_context {
     int*             d_pool_cand = nullptr;
     double*          d_pool_cand_upper = nullptr;
     psa::CandRec*    d_pool_rec = nullptr;
-    psa::SearchTail* d_pool_tail = nullptr;
     int              pool_cap = 0;
     std::vector<hipEvent_t> pool_events;
 
@@ -576,7 +578,11 @@ psa_status ensure_tails(psa_context* c, int count)
     if (c->h_tails) PSA_HIP(hipHostFree(c->h_tails));
     c->h_tails = nullptr;
     c->tails_cap = 0;
-    PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_tails), sizeof(psa::SearchTail) * (size_t)count, hipHostMallocDefault));
+    PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_tails), sizeof(psa::SearchTail) * (size_t)count,
+                          hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_tails, 0, sizeof(psa::SearchTail) * (size_t)count);
+    PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->hd_tails), c->h_tails, 0));
+    for (auto& s : c->slot) s.d_tail = c->hd_tails;
     c->tails_cap = count;
     return PSA_OK;
 }
@@ -960,7 +966,6 @@ psa_status ensure_pool(psa_context* c, int nq)
         PSA_TRY(dev_alloc(&c->d_pool_cand, (size_t)nq * kCandCap));
         PSA_TRY(dev_alloc(&c->d_pool_cand_upper, (size_t)nq * kCandCap));
         PSA_TRY(dev_alloc(&c->d_pool_rec, (size_t)nq * kCandCap));
-        PSA_TRY(dev_alloc(&c->d_pool_tail, (size_t)nq));
         c->pool_cap = nq;
     }
     while ((int)c->pool_events.size() < nq) {
@@ -978,7 +983,6 @@ psa_status init_slot(SearchSlot& s)
     PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_cand), sizeof(int) * kCandCap));
     PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_cand_upper), sizeof(double) * kCandCap));
     PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_rec), sizeof(psa::CandRec) * kCandCap));
-    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_tail), sizeof(psa::SearchTail)));
     PSA_HIP(hipEventCreateWithFlags(&s.front_done, hipEventDisableTiming));
     PSA_HIP(hipEventCreateWithFlags(&s.back_done, hipEventDisableTiming));
     return PSA_OK;
@@ -996,7 +1000,6 @@ void free_slot(SearchSlot& s)
     (void)hipFree(s.d_cand);
     (void)hipFree(s.d_cand_upper);
     (void)hipFree(s.d_rec);
-    (void)hipFree(s.d_tail);
     if (s.front_done) (void)hipEventDestroy(s.front_done);
     if (s.back_done) (void)hipEventDestroy(s.back_done);
 }
@@ -1093,7 +1096,6 @@ void psa_destroy(psa_context* c)
     (void)hipFree(c->d_pool_cand);
     (void)hipFree(c->d_pool_cand_upper);
     (void)hipFree(c->d_pool_rec);
-    (void)hipFree(c->d_pool_tail);
     for (auto& ev : c->pool_events) (void)hipEventDestroy(ev);
     if (c->h_tails) (void)hipHostFree(c->h_tails);
     if (c->h_bad) (void)hipHostFree(c->h_bad);
@@ -1168,6 +1170,7 @@ psa_status psa_search_async(psa_context* c, int first, int last)
     PSA_TRY(ensure_device(c));
     c->timing_valid = false;
     c->seq += 1;
+    s.d_tail = c->hd_tails;
     if (c->profiling) PSA_HIP(hipEventRecord(c->ev[0], c->stream));
     c->pending_filter = use_filter(c, first, last, s.m);
     c->pending_first = first;
@@ -1182,7 +1185,6 @@ psa_status psa_search_async(psa_context* c, int first, int last)
     } else {
         PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream, primary_tables(c)));
     }
-    PSA_HIP(hipMemcpyAsync(&c->h_tails[0], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
     if (c->profiling) {
         PSA_HIP(hipEventRecord(c->ev[1], c->stream));
         c->timing_valid = true;
@@ -1211,7 +1213,6 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
         c->fallbacks += 1;
         c->seq += 1;
         PSA_TRY(launch_sequential(c, c->slot[0], c->pending_first, c->pending_last, nullptr, nullptr, c->stream, primary_tables(c)));
-        PSA_HIP(hipMemcpyAsync(&c->h_tails[0], c->slot[0].d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
         PSA_HIP(hipStreamSynchronize(c->stream));
         c->timing_valid = false;
     }
@@ -1246,6 +1247,7 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
         set_last_error("psa_search_batch: bad arguments");
         return PSA_ERR_ARG;
     }
+    if (c->pending) { set_last_error("psa_search_batch: a psa_search_async is still in flight"); return PSA_ERR_STATE; }
     PSA_TRY(check_ready(c, m, first, last));
     PSA_TRY(ensure_device(c));
     const int nmodes = results1 ? 2 : 1;
@@ -1294,7 +1296,7 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
         v.d_cand = c->d_pool_cand + e * kCandCap;
         v.d_cand_upper = c->d_pool_cand_upper + e * kCandCap;
         v.d_rec = c->d_pool_rec + e * kCandCap;
-        v.d_tail = c->d_pool_tail + e;
+        v.d_tail = c->hd_tails + e;
         v.front_done = c->pool_events[e];
         v.m = m;
         v.s2rows = c->d_batch_rows + (size_t)q * ostride;
@@ -1311,10 +1313,8 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
             PSA_HIP(hipEventRecord(s0.front_done, front));
             PSA_HIP(hipStreamWaitEvent(c->aux, s0.front_done, 0));
             PSA_TRY(launch_filter_back(c, s0, pairs, c->aux, tables[0], c->batch_rescore_grid));
-            PSA_HIP(hipMemcpyAsync(&c->h_tails[q], s0.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->aux));
             if (nmodes == 2) {
                 PSA_TRY(launch_filter_back(c, s1, pairs, c->aux, tables[1], c->batch_rescore_grid));
-                PSA_HIP(hipMemcpyAsync(&c->h_tails[nq + q], s1.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->aux));
             }
         }
     } else {
@@ -1324,6 +1324,7 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
                 SearchSlot& s = c->slot[k % kSlots];
                 if (k >= kSlots) PSA_HIP(hipStreamWaitEvent(c->stream, s.back_done, 0));   // slot free again
                 s.m = m;
+                s.d_tail = c->hd_tails + k;
                 s.s2rows = c->d_batch_rows + (size_t)q * ostride;
                 s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
                 c->seq = seq_of(mode, q);
@@ -1337,7 +1338,6 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
                     PSA_HIP(hipEventRecord(s.front_done, c->stream));
                     PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
                 }
-                PSA_HIP(hipMemcpyAsync(&c->h_tails[k], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->aux));
                 PSA_HIP(hipEventRecord(s.back_done, c->aux));
             }
     }
@@ -1357,16 +1357,19 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
                 c->seq += 1;
                 for (auto& sl : c->slot) sl.scal_dirty = true;
                 s.m = m;
+                s.d_tail = c->hd_tails + k;
                 s.s2rows = c->d_batch_rows + (size_t)q * ostride;
                 s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
                 PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream, tables[mode]));
-                PSA_HIP(hipMemcpyAsync(&c->h_tails[k], s.d_tail, sizeof(psa::SearchTail), hipMemcpyDeviceToHost, c->stream));
                 PSA_HIP(hipStreamSynchronize(c->stream));
             }
             results[mode][q] = c->h_tails[k].result;
             results[mode][q].shard = q;
         }
-    for (auto& s : c->slot) s.m = -1;      // the single-search Seq2 is gone
+    for (auto& s : c->slot) {
+        s.m = -1;                          // the single-search Seq2 is gone
+        s.d_tail = c->hd_tails;
+    }
     return PSA_OK;
 }
 

@@ -2,7 +2,8 @@
 """Condenses rocprofv3 output dirs (gpurun_out/prof_*) into committed summaries.
 
   python tools/collect_profiles.py <tag>      e.g. r01_seq
-writes profiles/<tag>_kernel_stats.csv  (rocprofv3 --kernel-trace --stats summary, verbatim)
+writes profiles/<tag>_kernel_stats.csv  (rocprofv3 --kernel-trace --stats summary, verbatim; from prof_stats/)
+       profiles/<tag>_twin_kernel_stats.csv  (the same from prof_stats_twin/, if present)
        profiles/<tag>_counters.csv      (mean of every PMC counter per kernel, one pass per counter set)
 and updates profiles/hbm_traffic.json   (per-launch HBM bytes of each psa kernel:
        (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — FETCH_SIZE/WRITE_SIZE are in KiB and gfx950's FETCH_SIZE
@@ -28,6 +29,10 @@ def main():
     stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))
     if stats:
         shutil.copy(stats[0], os.path.join(OUT, f"{tag}_kernel_stats.csv"))
+    # the default batch (count kernels of consecutive queries overlap on two streams)
+    twin = glob.glob(os.path.join(src, "prof_stats_twin", "*", "*_kernel_stats.csv"))
+    if twin:
+        shutil.copy(twin[0], os.path.join(OUT, f"{tag}_twin_kernel_stats.csv"))
     acc = collections.defaultdict(list)
     for f in glob.glob(os.path.join(src, "prof_*", "*", "*_counter_collection.csv")):
         for row in csv.DictReader(open(f)):
