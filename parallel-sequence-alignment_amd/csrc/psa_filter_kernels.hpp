@@ -668,7 +668,10 @@ struct RescoreArgs {
     int fast_min_exp;               // smallest biased exponent of the running sum the walk handles
 };
 
-constexpr int kRescoreEpl = 8;          // chars per lane and batch on the integer walk
+#ifndef PSA_RESCORE_EPL
+#define PSA_RESCORE_EPL 8
+#endif
+constexpr int kRescoreEpl = PSA_RESCORE_EPL;   // chars per lane and batch on the integer walk
 constexpr int kRescoreThreads = 512;
 constexpr int kRescoreChunk = 32768;    // chars whose class codes are staged in LDS at a time
 constexpr int kRescoreGrid = 64;        // workgroups; each takes candidates ci = block, block + 64, ...
@@ -715,6 +718,12 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     __shared__ int s_last;
     extern __shared__ unsigned char s_pad[];      // never touched: only makes the workgroup too big to share a
     (void)s_pad;                                  // CU with a count-kernel workgroup (LDS), see launch site
+#ifdef PSA_PHASE_TIMING
+#define PSA_RPHASE(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_ts[1000][k] = wall_clock64(); } while (0)
+#else
+#define PSA_RPHASE(k) do { } while (0)
+#endif
+    PSA_RPHASE(0);
     int count = *a.cand_count;
     if (count > a.cap) count = a.cap;
     const int tid = threadIdx.x;
@@ -723,6 +732,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     for (int k = tid; k < kRow * kRow; k += kRescoreThreads) s_clsrank[k] = a.clsrank[k];
     __syncthreads();
     const double final_best = key_order(*a.global_best);
+    PSA_RPHASE(1);
     for (int ci = blockIdx.x; ci < count; ci += gridDim.x) {
     // candidates were picked against a running best; drop those the final best rules out
     const bool pruned = a.cand_upper != nullptr && a.cand_upper[ci] < final_best;
@@ -760,6 +770,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
             }
         }
         __syncthreads();
+        if (ci == (int)blockIdx.x) PSA_RPHASE(2);
         // ---- sum the chunk in reference order (wave 0)
         if (tid < 64) {
             int k = c0;
@@ -809,43 +820,55 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
                 long long S = (long long)((sb & 0xfffffffffffffull) | (1ull << 52));
                 const bool neg = (sb >> 63) != 0;
                 if (neg) S = -S;
-                const long long lo = 1ll << 52, hi = 1ll << 53;
+                // |q| strictly inside (2^52, 2^53)  <=>  q strictly inside (bound_lo, bound_hi)
+                const long long bound_lo = neg ? -(1ll << 53) : (1ll << 52);
+                const long long bound_hi = neg ? -(1ll << 52) : (1ll << 53);
+                static_assert(kRescoreEpl == 8, "a lane's codes of one batch are one 8-byte LDS word");
                 bool left = false;
                 while (k < c1 && !left) {
-                    const unsigned char* codes = s_codes + (k - c0) + lane * kRescoreEpl;
+                    // The batch starts at the 8-aligned position at or below k; chars below k are already in
+                    // S and count as padding (class 4, addend 0), like the staged positions past c1.
+                    const int k_al = k & ~7;
+                    unsigned long long w = *reinterpret_cast<const unsigned long long*>(s_codes + (k_al - c0) + lane * 8);
+                    if (lane == 0 && k != k_al) {
+                        const unsigned long long keep = ~0ull << (8 * (k - k_al));
+                        w = (w & keep) | (0x0404040404040404ull & ~keep);
+                    }
                     long long rr[kRescoreEpl];
                     long long t = 0;
 #pragma unroll
                     for (int j = 0; j < kRescoreEpl; ++j) {
-                        unsigned cls = codes[j] & 7u;
-                        if (k + lane * kRescoreEpl + j >= c1) cls = 4u;     // the next chunk's chars are not staged yet
-                        rr[j] = s_round[cls];
+                        rr[j] = s_round[(unsigned)(w >> (8 * j)) & 7u];
                         t += rr[j];
                     }
                     const long long incl = wave_scan_inclusive(t);
-                    long long q = S + (incl - t);                 // sum before this lane's first char
-                    long long before[kRescoreEpl];
-                    int bad = kRescoreEpl;
+                    const long long q0 = S + (incl - t);          // sum before this lane's first char
+                    long long q = q0;
+                    bool inside = true;
 #pragma unroll
                     for (int j = 0; j < kRescoreEpl; ++j) {
-                        before[j] = q;
                         q += rr[j];
-                        const long long mag = neg ? -q : q;
-                        if (!(mag > lo && mag < hi) && bad == kRescoreEpl) bad = j;
+                        inside &= (q > bound_lo) & (q < bound_hi);
                     }
-                    const unsigned long long bad_lanes = __ballot(bad < kRescoreEpl);
+                    const unsigned long long bad_lanes = __ballot(!inside);
                     if (bad_lanes == 0ull) {
                         S = readlane64(q, 63);
-                        const int nb = c1 - k < 64 * kRescoreEpl ? c1 - k : 64 * kRescoreEpl;
-                        k += nb;
+                        k = k_al + 64 * kRescoreEpl < c1 ? k_al + 64 * kRescoreEpl : c1;
                     } else {
+                        // rare (once per binade change): find the first char that leaves the binade
+                        int bad = kRescoreEpl;
+                        long long prev = q0, run = q0;
+#pragma unroll
+                        for (int j = 0; j < kRescoreEpl; ++j) {
+                            const long long nxt = run + rr[j];
+                            if (!((nxt > bound_lo) & (nxt < bound_hi)) && bad == kRescoreEpl) { bad = j; prev = run; }
+                            run = nxt;
+                        }
                         const int L = __ffsll((long long)bad_lanes) - 1;
                         const int j = __builtin_amdgcn_readlane(bad, L);
-                        long long prev = before[0];
-#pragma unroll
-                        for (int jj = 1; jj < kRescoreEpl; ++jj) prev = jj == j ? before[jj] : prev;
                         S = readlane64(prev, L);                  // the sum before the char that leaves the binade
-                        k += L * kRescoreEpl + j;
+                        const int p = k_al + L * kRescoreEpl + j;
+                        k = p > k ? p : k;                        // (a skipped char can only "fail" with S on the binade's edge)
                         left = true;
                     }
                 }
@@ -860,6 +883,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if (ci == (int)blockIdx.x) PSA_RPHASE(3);
         __syncthreads();            // the next chunk overwrites s_codes
     }
 
@@ -894,6 +918,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
         r.score = 0.0; r.offset = -1; r.char_offset = -1; r.rank = 0; r.ch = 0;     // rank 0: ignored by the fold
         a.rec[ci] = r;
     }
+    if (ci == (int)blockIdx.x) PSA_RPHASE(4);
     // ---- the last candidate workgroup to finish folds all records (is_swapable order).
     // Hand-off per the release/acquire rule: record store -> agent-scope release ->
     // relaxed atomic arrival; the last arriver acquires before reading the records.
@@ -951,6 +976,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
         }
     }
     __syncthreads();            // the next candidate reuses the shared buffers
+    if (ci == (int)blockIdx.x) PSA_RPHASE(5);
     }
 }
 

@@ -30,6 +30,9 @@ def psa():
     if not os.path.exists(lib_path):
         import __graft_entry__
         __graft_entry__.build()
+    # torch first: its wheel bundles its own HIP runtime, which must be the first one initialised in a
+    # process that also uses torch.cuda (the tests with device-resident inputs); libpsa_amd.so links /opt/rocm's
+    import torch  # noqa: F401
     import psa_amd
     return psa_amd
 

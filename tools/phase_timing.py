@@ -35,3 +35,11 @@ for k, name in enumerate(names):
     d = (ts[:, k + 1] - ts[:, k]) / 100.0
     print(f"{name:22s} mean {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
 print("result", r)
+
+# re-score kernel (workgroup 0, its first candidate)
+ctx.debug_rescore(np.array([r.offset, 5, 77777], dtype=np.int32))
+assert lib.psa_debug_phase_ts(buf) == 0
+ts = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)[1000]
+names = ["start -> tables + scalars", "classify (all waves)", "walk (wave 0)", "key reduce + record", "arrive + fold + tail"]
+for k, name in enumerate(names):
+    print(f"rescore {name:28s} {(ts[k + 1] - ts[k]) / 100.0:7.2f} us")
