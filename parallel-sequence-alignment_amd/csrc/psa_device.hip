@@ -1267,18 +1267,22 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
         PSA_TRY(dev_alloc(&c->d_batch_bytes, (size_t)nq * ostride));
         c->batch_cap = (size_t)nq * ostride;
     }
-    hipLaunchKernelGGL(psa::psa_encode_batch_kernel, dim3((ostride + 255) / 256, nq), dim3(256), 0, c->stream,
-                       base, nq, m, stride, c->d_batch_rows, c->d_batch_bytes, ostride, c->d_bad);
-    PSA_HIP(hipGetLastError());
     // single-chunk filter plans keep all per-query state in pools (entry mode*nq + q): nothing is
     // reused inside the batch and the count kernels never wait for the re-score stream
     FilterPlan plan;
     const bool pooled = filter && plan_filter(first, last, m, &plan) && plan.nchunks == 1;
+    static_assert(sizeof(Scalars) % sizeof(unsigned long long) == 0, "the encode kernel zeroes the pool in 8-byte words");
+    int zero_words = 0;
     if (pooled) {
         PSA_TRY(ensure_pool(c, nq * nmodes));
-        PSA_HIP(hipMemsetAsync(c->d_pool_scal, 0, sizeof(Scalars) * (size_t)nq * nmodes, c->stream));
+        zero_words = (int)(sizeof(Scalars) / sizeof(unsigned long long)) * nq * nmodes;     // << threads of the encode grid
+    } else {
+        for (auto& s : c->slot) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
     }
-    for (auto& s : c->slot) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
+    hipLaunchKernelGGL(psa::psa_encode_batch_kernel, dim3((ostride + 255) / 256, nq), dim3(256), 0, c->stream,
+                       base, nq, m, stride, c->d_batch_rows, c->d_batch_bytes, ostride, c->d_bad,
+                       reinterpret_cast<unsigned long long*>(c->d_pool_scal), zero_words);
+    PSA_HIP(hipGetLastError());
     // the other streams must see everything already enqueued on the main stream (Seq1 codes, tables, query codes)
     hipEvent_t& gate = c->slot[0].front_done;
     PSA_HIP(hipEventRecord(gate, c->stream));

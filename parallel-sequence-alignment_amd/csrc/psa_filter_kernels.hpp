@@ -99,10 +99,14 @@ struct SlicedCounter {
 __global__ __launch_bounds__(256) void psa_encode_batch_kernel(const unsigned char* __restrict__ raw, int nq, int m,
                                                                size_t in_stride, unsigned int* __restrict__ rows,
                                                                unsigned char* __restrict__ bytes, int out_stride,
-                                                               int* __restrict__ bad)
+                                                               int* __restrict__ bad,
+                                                               unsigned long long* __restrict__ zero, int zero_words)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int q = blockIdx.y;
+    // the batch's per-query search scalars start from zero (saves a fill command in front of the batch)
+    const long long g = ((long long)q * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+    if (g < zero_words) zero[g] = 0ull;
     if (i >= out_stride || q >= nq) return;
     int code = kCodePad;
     if (i < m) {
