@@ -18,6 +18,14 @@
  * record of input.txt (the reference's file holds 15, it only ever reads the
  * first) and writes one "<mutated seq2>\n<offset> <score>" block per record,
  * blocks separated by a newline.
+ *
+ * Extension: `psa_main --pretty [percentage]` also prints the
+ * reference's human-checkable view of the answer (pretty_print,
+ * cpu_funcs.c:382-426, its DEBUG_PRINT build): mode, weights, the score and
+ * sign string of the winning offset before and after the mutation, with the
+ * mutated position in red.  The scores of that view come from a second,
+ * independent host-side scorer (get_score_and_signs, cpu_funcs.c:430-443)
+ * over the library's sign table.
  */
 #include <math.h>
 #include <stdio.h>
@@ -43,6 +51,69 @@ static int read_token(FILE* f, char* dst, size_t cap)
 }
 
 static ProgramData g_data;   /* ~1 MB: kept off the stack */
+
+/* ---- the verification view (pretty_print, cpu_funcs.c:382-461) ---- */
+static char   g_sign[32 * 32];
+static double g_pair[32 * 32];
+
+static int symbol_index(char c) { return c == PSA_HYPHEN ? 26 : (c >= 'A' && c <= 'Z' ? c - 'A' : -1); }
+
+/* score and sign string of seq2 under seq1 at `offset` (get_score_and_signs, cpu_funcs.c:430-443) */
+static double score_and_signs(const char* seq1, const char* seq2, int offset, char* signs)
+{
+    double score = 0.0;
+    size_t i;
+    for (i = 0; seq2[i] != '\0'; ++i) {
+        const int a = symbol_index(seq1[offset + i]), b = symbol_index(seq2[i]);
+        if (a < 0 || b < 0) { signs[i] = '?'; continue; }
+        signs[i] = g_sign[a * 32 + b];
+        score += g_pair[a * 32 + b];
+    }
+    signs[i] = '\0';
+    return score;
+}
+
+/* the string shifted right by `offset`, the char at char_offset in red (print_with_offset, cpu_funcs.c:446-461) */
+static void print_with_offset(const char* chrs, int offset, int char_offset)
+{
+    const size_t len = strlen(chrs);
+    size_t i;
+    if (char_offset < 0) char_offset = 0;
+    for (i = 0; i < (size_t)offset; ++i) putchar(' ');
+    for (i = 0; i < (size_t)char_offset && i < len; ++i) putchar(chrs[i]);
+    if ((size_t)char_offset < len) printf("\033[0;31m%c\033[0m", chrs[char_offset]);
+    for (i = (size_t)char_offset + 1; i < len; ++i) putchar(chrs[i]);
+}
+
+static void pretty_print(const ProgramData* data, const char* mut, int offset, int char_offset)
+{
+    static char signs[PSA_SEQ2_MAX_LEN];
+    double score;
+    int i;
+    if (psa_build_tables(data->weights, data->is_max, g_pair, NULL, NULL, g_sign) != PSA_OK) return;
+    printf("\033[0;31m%s\033[0m problem\n", data->is_max ? "Maximum" : "Minimum");
+    printf("Weights: ");
+    for (i = 0; i < PSA_NUM_WEIGHTS; ++i) printf("%g ", data->weights[i]);
+    if (offset == -1) {
+        printf("\n\033[0;31mThere are no mutations found\033[0m\n");
+        printf("%s\n%s\n", data->seq1, data->seq2);
+        return;
+    }
+    score = score_and_signs(data->seq1, data->seq2, offset, signs);
+    printf("\nOriginal Score: %g\n", score);
+    print_with_offset(signs, offset, char_offset);
+    printf("\n");
+    print_with_offset(data->seq2, offset, char_offset);
+    printf("\n");
+    printf("%s\n", data->seq1);
+    print_with_offset(mut, offset, char_offset);
+    printf("\n");
+    score = score_and_signs(data->seq1, mut, offset, signs);
+    print_with_offset(signs, offset, char_offset);
+    printf("\n");
+    printf("Mutation Score: %g\n", score);
+    printf("Seq offset=%3d, Char offset=%3d\n", offset, char_offset);
+}
 
 static int run_all_records(void)
 {
@@ -100,9 +171,16 @@ int main(int argc, char* argv[])
     struct timespec t0, t1;
     static char mut[PSA_SEQ2_MAX_LEN];
 
+    int pretty = 0;
+    const char* percentage = argc == 2 ? argv[1] : NULL;
+
     if (argc == 2 && strcmp(argv[1], "--all") == 0) return run_all_records();
-    if (argc == 2) {
-        int v = atoi(argv[1]);
+    if (argc >= 2 && strcmp(argv[1], "--pretty") == 0) {
+        pretty = 1;
+        percentage = argc == 3 ? argv[2] : NULL;
+    }
+    if (percentage) {
+        int v = atoi(percentage);
         if (v >= 0 && v <= 100) cuda_percentage = v;
     }
 
@@ -152,5 +230,6 @@ int main(int argc, char* argv[])
     fclose(out);
 
     printf("total time: %g\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+    if (pretty) pretty_print(&g_data, mut, mutant.offset, mutant.char_offset);
     return 0;
 }

@@ -546,6 +546,43 @@ def test_drop_in_program(psa, tmp_path):
     assert run.returncode == 2 and "Error open input file" in run.stdout
 
 
+def test_drop_in_program_pretty_view(psa, oracle, reference_records, tmp_path):
+    """psa_main --pretty: the reference's verification view (pretty_print, cpu_funcs.c:382-426): scores and sign
+    strings of the winning offset before/after the mutation == the oracle's get_score_and_signs."""
+    import re
+    import shutil
+    import subprocess
+    from conftest import PKG
+    exe = os.path.join(PKG, "host", "psa_main")
+    shutil.copy(os.path.join(GOLDEN, "reference_input.txt"), tmp_path / "input.txt")
+    run = subprocess.run([exe, "--pretty", "100"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert (tmp_path / "output.txt").read_bytes() == open(os.path.join(GOLDEN, "reference_output.txt"), "rb").read()
+    w, s1, s2, is_max = reference_records[0]
+    score, off, ci, ch = oracle.search(s1, s2, w, is_max, threads=8)
+    mut = bytearray(s2)
+    mut[ci] = ord(ch)
+    before, signs_before = oracle.score_and_signs(s1, s2, w, off)
+    after, signs_after = oracle.score_and_signs(s1, bytes(mut), w, off)
+    red = "\033[0;31m"
+    assert (red + ("Maximum" if is_max else "Minimum") + "\033[0m problem") in run.stdout
+    lines = re.sub(r"\033\[[0-9;]*m", "", run.stdout).splitlines()
+    k = next(i for i, line in enumerate(lines) if line.endswith(" problem"))
+    assert lines[k + 1] == "Weights: " + "".join("%g " % x for x in w)
+    pad = " " * off
+    assert lines[k + 2] == "Original Score: %g" % before
+    assert lines[k + 3] == pad + signs_before
+    assert lines[k + 4] == pad + s2.decode()
+    assert lines[k + 5] == s1.decode()
+    assert lines[k + 6] == pad + mut.decode()
+    assert lines[k + 7] == pad + signs_after
+    assert lines[k + 8] == "Mutation Score: %g" % after
+    assert lines[k + 9] == "Seq offset=%3d, Char offset=%3d" % (off, ci)
+    # the mutated position is the red one on the Seq2 line
+    raw = run.stdout.splitlines()[k + 4]
+    assert raw == pad + s2.decode()[:ci] + red + s2.decode()[ci] + "\033[0m" + s2.decode()[ci + 1:]
+
+
 def test_long_seq2_multi_chunk_path(psa, oracle):
     """|Seq2| above one workgroup's reach (16 waves x 992 chars): several char chunks, partial counts
     combined by psa_keys_kernel / psa_select_kernel; also a short range that spreads chunks to fill the GPU."""
