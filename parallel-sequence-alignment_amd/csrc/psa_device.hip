@@ -327,6 +327,7 @@ struct FilterPlan {
     int chunk_chars = 0;
     int wave_chars = 0;
     int lds_slots = 0;
+    int row_slots = 0;    // distance of two plane rows in LDS (kRowSlots for 16 waves, packed for 8)
     int lds_bytes = 0;
     int ntiles = 0;       // offset tiles (grid.x)
 };
@@ -352,9 +353,8 @@ struct SearchSlot {
     bool                inline_select = false; // the count kernel picked the candidates itself
     bool                scal_dirty = false;    // a filter search was enqueued and its self-reset not confirmed yet
     psa::BlockRec*      d_blocks = nullptr;    int blocks_cap = 0;      // sequential engine
-    unsigned long long* d_partial = nullptr;   size_t partial_cap = 0;
-    double*             d_upper = nullptr;     size_t upper_cap = 0;
-    unsigned long long* d_block_best = nullptr; int block_best_cap = 0;
+    unsigned long long* d_partial = nullptr;   size_t partial_cap = 0;   // [nchunks][span_pad] counts of a multi-chunk search
+    int*                d_arrivals = nullptr;  int arrivals_cap = 0;     // [ntiles], zero between searches
     Scalars*            d_scal = nullptr;
     int*                d_cand = nullptr;
     double*             d_cand_upper = nullptr;
@@ -413,6 +413,9 @@ struct psa_context {
     psa::CandRec*    d_pool_rec = nullptr;
     int              pool_cap = 0;
     std::vector<hipEvent_t> pool_events;
+    // count-kernel scratch of multi-chunk plans inside a batch: kernels q and q+2 share a stream, so two sets do
+    unsigned long long* d_ring_partial[2] = {nullptr, nullptr};   size_t ring_partial_cap = 0;
+    int*                d_ring_arrivals[2] = {nullptr, nullptr};  int ring_arrivals_cap = 0;
 
     SearchSlot  slot[kSlots];
 
@@ -688,8 +691,10 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
             const int wave_chars = chunk / waves;
             if (wave_chars > psa::kMaxWaveChars) continue;
             const int slots = chunk / 32 + 129;
-            if (slots > psa::kRowSlots) continue;             // rows are kRowSlots slots apart in LDS
-            int lds = psa::kMaskRows * psa::kRowSlots * 8;
+            if (slots > psa::kRowSlots) continue;             // rows are at most kRowSlots slots apart in LDS
+            // 16 waves: rows 4 KiB apart (a symbol is its row offset); 8 waves: rows packed, two workgroups per CU
+            const int row_slots = waves == 16 ? psa::kRowSlots : slots;
+            int lds = psa::kMaskRows * row_slots * 8;
             if (exchange_bytes(waves) > lds) lds = exchange_bytes(waves);
             if (publish > lds) lds = publish;
             if (lds > kLdsLimit) continue;
@@ -698,9 +703,11 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
             if (per_cu > 16 / waves) per_cu = 16 / waves;
             const long long blocks = (long long)ntiles * nchunks;
             const long long rounds = (blocks + 256 * per_cu - 1) / (256 * per_cu);   // waves of co-resident workgroups
-            // VALU-bound: ~12.3 CU-cycles per char of a workgroup, plus staging and the epilogue
-            const double block_cost = 12.3 * chunk + 0.5 * psa::kMaskRows * slots + 4000.0;
-            const double cost = (double)rounds * per_cu * block_cost;
+            // VALU-bound: ~12.3 CU-cycles per char of a workgroup alone on its CU, plus staging and the epilogue; the
+            // chunk workgroups of a tile meet through memory (stores, L2 write-back, arrival, read-back: ~10 us)
+            const double block_cost = 12.3 * chunk * per_cu + 0.5 * psa::kMaskRows * slots + 4000.0 +
+                                      (nchunks > 1 ? 20000.0 : 0.0);
+            const double cost = (double)rounds * block_cost;     // co-resident workgroups share the CU's VALU
             if (!found || cost < best_cost) {
                 found = true;
                 best_cost = cost;
@@ -709,6 +716,7 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
                 best->chunk_chars = chunk;
                 best->wave_chars = wave_chars;
                 best->lds_slots = slots;
+                best->row_slots = row_slots;
                 best->lds_bytes = lds;
                 best->ntiles = ntiles;
             }
@@ -751,6 +759,7 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
                         int span, bool inline_select, hipStream_t stream, const TableSet& ts,
                         const SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr)
 {
+    if (p.nchunks > 1 && inline_select && !s.d_arrivals) { set_last_error("internal: no arrival counters"); return PSA_ERR_STATE; }
     psa::CountArgs a;
     a.s1 = c->d_s1;
     a.symbol_planes = c->d_symbol_planes;
@@ -761,6 +770,9 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.chunk_chars = p.chunk_chars;
     a.wave_chars = p.wave_chars;
     a.lds_slots = p.lds_slots;
+    a.row_slots = p.row_slots;
+    a.row_mul = (unsigned)(8 * p.row_slots) << 20;
+    a.tile_arrivals = s.d_arrivals;
     a.inline_select = inline_select ? 1 : 0;
     a.nmodes = s2 ? 2 : 1;
     a.cap = kCandCap;
@@ -804,73 +816,48 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     return PSA_OK;
 }
 
-// count (+ bounds) and candidate selection
-psa_status launch_filter_front(psa_context* c, SearchSlot& s, int first, int last, hipStream_t stream, bool profile,
-                               const TableSet& ts, SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr)
+// Scratch of a multi-chunk plan: per-chunk counts of every offset and the tiles' arrival counters.
+psa_status ensure_chunk_scratch(unsigned long long** partial, size_t* partial_cap, int** arrivals, int* arrivals_cap,
+                                const FilterPlan& p, hipStream_t stream)
 {
-    const int span = last - first;
-    const int base = first & ~31;
-    FilterPlan p;
-    if (!plan_filter(first, last, s.m, &p)) {
+    const size_t need = (size_t)p.nchunks * p.ntiles * psa::kTile;
+    if (need > *partial_cap) {
+        *partial_cap = 0;
+        PSA_TRY(dev_alloc(partial, need));
+        *partial_cap = need;
+    }
+    if (p.ntiles > *arrivals_cap) {
+        *arrivals_cap = 0;
+        PSA_TRY(dev_alloc(arrivals, (size_t)p.ntiles));
+        PSA_HIP(hipMemsetAsync(*arrivals, 0, sizeof(int) * (size_t)p.ntiles, stream));   // the kernels leave them zero
+        *arrivals_cap = p.ntiles;
+    }
+    return PSA_OK;
+}
+
+// the plan of a search on a slot's own scratch buffers
+psa_status plan_on_slot(SearchSlot& s, int first, int last, hipStream_t stream, FilterPlan* p)
+{
+    if (!plan_filter(first, last, s.m, p)) {
         set_last_error("internal: no filter plan fits the LDS");
         return PSA_ERR_ARG;
     }
+    if (p->nchunks > 1) PSA_TRY(ensure_chunk_scratch(&s.d_partial, &s.partial_cap, &s.d_arrivals, &s.arrivals_cap, *p, stream));
+    return PSA_OK;
+}
+
+// count + bounds + candidate selection: one kernel (chunk workgroups of a tile combine in the kernel)
+psa_status launch_filter_front(psa_context* c, SearchSlot& s, const FilterPlan& p, int first, int last, hipStream_t stream,
+                               bool profile, const TableSet& ts, SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr)
+{
+    const int span = last - first;
+    const int base = first & ~31;
     const int span_pad = p.ntiles * psa::kTile;
-    s.inline_select = p.nchunks == 1;
-    if (s2) {
-        if (!s.inline_select) { set_last_error("internal: two-mode selection needs a single-chunk plan"); return PSA_ERR_ARG; }
-        s2->inline_select = true;
-    }
+    s.inline_select = true;
+    if (s2) s2->inline_select = true;
     if (profile) PSA_HIP(hipEventRecord(c->ev[2], stream));
-    if (s.inline_select) {
-        PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, true, stream, ts, s2, ts2));
-        if (profile) PSA_HIP(hipEventRecord(c->ev[3], stream));
-        return PSA_OK;
-    }
-    // several char chunks: partial counts -> keys kernel -> select kernel
-    const size_t need_partial = (size_t)p.nchunks * span_pad;
-    if (need_partial > s.partial_cap) {
-        s.partial_cap = 0;
-        PSA_TRY(dev_alloc(&s.d_partial, need_partial));
-        s.partial_cap = need_partial;
-    }
-    if ((size_t)span > s.upper_cap) {
-        s.upper_cap = 0;
-        PSA_TRY(dev_alloc(&s.d_upper, (size_t)span));
-        s.upper_cap = (size_t)span;
-    }
-    if (psa::kKeyBlocks > s.block_best_cap) {
-        s.block_best_cap = 0;
-        PSA_TRY(dev_alloc(&s.d_block_best, (size_t)psa::kKeyBlocks));
-        s.block_best_cap = psa::kKeyBlocks;
-    }
-    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, false, stream, ts));
+    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, true, stream, ts, s2, ts2));
     if (profile) PSA_HIP(hipEventRecord(c->ev[3], stream));
-
-    psa::KeyArgs k;
-    k.partial = s.d_partial;
-    k.upper = s.d_upper;
-    k.block_best = s.d_block_best;
-    k.bounds = bound_params(*ts.t, s.m);
-    k.nchunks = p.nchunks;
-    k.span_pad = span_pad;
-    k.span = span;
-    k.lead = first - base;
-    const int nbest = std::min(psa::kKeyBlocks, (span + 255) / 256);
-    hipLaunchKernelGGL(psa::psa_keys_kernel, dim3(nbest), dim3(256), 0, stream, k);
-    PSA_HIP(hipGetLastError());
-
-    psa::SelectArgs sel;
-    sel.upper = s.d_upper;
-    sel.block_best = s.d_block_best;
-    sel.nbest = nbest;
-    sel.cand = s.d_cand;
-    sel.cand_count = &s.d_scal->cand_count;
-    sel.span = span;
-    sel.first = first;
-    sel.cap = kCandCap;
-    hipLaunchKernelGGL(psa::psa_select_kernel, dim3(nbest), dim3(256), 0, stream, sel);
-    PSA_HIP(hipGetLastError());
     return PSA_OK;
 }
 
@@ -994,8 +981,7 @@ void free_slot(SearchSlot& s)
     (void)hipFree(s.d_s2bytes);
     (void)hipFree(s.d_blocks);
     (void)hipFree(s.d_partial);
-    (void)hipFree(s.d_upper);
-    (void)hipFree(s.d_block_best);
+    (void)hipFree(s.d_arrivals);
     (void)hipFree(s.d_scal);
     (void)hipFree(s.d_cand);
     (void)hipFree(s.d_cand_upper);
@@ -1096,6 +1082,10 @@ void psa_destroy(psa_context* c)
     (void)hipFree(c->d_pool_cand);
     (void)hipFree(c->d_pool_cand_upper);
     (void)hipFree(c->d_pool_rec);
+    for (int k = 0; k < 2; ++k) {
+        (void)hipFree(c->d_ring_partial[k]);
+        (void)hipFree(c->d_ring_arrivals[k]);
+    }
     for (auto& ev : c->pool_events) (void)hipEventDestroy(ev);
     if (c->h_tails) (void)hipHostFree(c->h_tails);
     if (c->h_bad) (void)hipHostFree(c->h_bad);
@@ -1180,7 +1170,9 @@ psa_status psa_search_async(psa_context* c, int first, int last)
         // enqueued but never waited for (or failed) can have left them dirty
         if (s.scal_dirty) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
         s.scal_dirty = true;
-        PSA_TRY(launch_filter_front(c, s, first, last, c->stream, c->profiling, primary_tables(c)));
+        FilterPlan plan;
+        PSA_TRY(plan_on_slot(s, first, last, c->stream, &plan));
+        PSA_TRY(launch_filter_front(c, s, plan, first, last, c->stream, c->profiling, primary_tables(c)));
         PSA_TRY(launch_filter_back(c, s, (long long)(last - first) * s.m, c->stream, primary_tables(c)));
     } else {
         PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream, primary_tables(c)));
@@ -1270,12 +1262,19 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
     // single-chunk filter plans keep all per-query state in pools (entry mode*nq + q): nothing is
     // reused inside the batch and the count kernels never wait for the re-score stream
     FilterPlan plan;
-    const bool pooled = filter && plan_filter(first, last, m, &plan) && plan.nchunks == 1;
+    const bool pooled = filter && plan_filter(first, last, m, &plan);
     static_assert(sizeof(Scalars) % sizeof(unsigned long long) == 0, "the encode kernel zeroes the pool in 8-byte words");
     int zero_words = 0;
     if (pooled) {
         PSA_TRY(ensure_pool(c, nq * nmodes));
         zero_words = (int)(sizeof(Scalars) / sizeof(unsigned long long)) * nq * nmodes;     // << threads of the encode grid
+        if (plan.nchunks > 1)
+            for (int k = 0; k < 2; ++k) {
+                size_t cap = c->ring_partial_cap;
+                int acap = c->ring_arrivals_cap;
+                PSA_TRY(ensure_chunk_scratch(&c->d_ring_partial[k], &cap, &c->d_ring_arrivals[k], &acap, plan, c->stream));
+                if (k == 1) { c->ring_partial_cap = cap; c->ring_arrivals_cap = acap; }
+            }
     } else {
         for (auto& s : c->slot) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
     }
@@ -1305,6 +1304,8 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
         v.m = m;
         v.s2rows = c->d_batch_rows + (size_t)q * ostride;
         v.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
+        v.d_partial = c->d_ring_partial[q & 1];          // queries q and q+2 run on the same stream
+        v.d_arrivals = c->d_ring_arrivals[q & 1];
         return v;
     };
     if (pooled) {
@@ -1313,7 +1314,7 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
             SearchSlot s0 = pool_view(0, q);
             SearchSlot s1 = pool_view(nmodes - 1, q);
             c->seq = seq0 + q;
-            PSA_TRY(launch_filter_front(c, s0, first, last, front, false, tables[0], nmodes == 2 ? &s1 : nullptr, &tables[1]));
+            PSA_TRY(launch_filter_front(c, s0, plan, first, last, front, false, tables[0], nmodes == 2 ? &s1 : nullptr, &tables[1]));
             PSA_HIP(hipEventRecord(s0.front_done, front));
             PSA_HIP(hipStreamWaitEvent(c->aux, s0.front_done, 0));
             PSA_TRY(launch_filter_back(c, s0, pairs, c->aux, tables[0], c->batch_rescore_grid));
@@ -1333,7 +1334,9 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
                 s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
                 c->seq = seq_of(mode, q);
                 if (filter) {
-                    PSA_TRY(launch_filter_front(c, s, first, last, c->stream, false, tables[mode]));
+                    FilterPlan sp;
+                    PSA_TRY(plan_on_slot(s, first, last, c->stream, &sp));
+                    PSA_TRY(launch_filter_front(c, s, sp, first, last, c->stream, false, tables[mode]));
                     PSA_HIP(hipEventRecord(s.front_done, c->stream));
                     PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
                     PSA_TRY(launch_filter_back(c, s, pairs, c->aux, tables[mode]));

@@ -300,11 +300,14 @@ struct CountArgs {
     int chunk_chars;  // chars per chunk (multiple of kUnroll * waves)
     int wave_chars;   // chars per wave   (multiple of kUnroll, <= kMaxWaveChars)
     int lds_slots;    // slots per staged row
+    int row_slots;    // distance of two rows in LDS, in slots (the 16-wave kernel uses kRowSlots)
+    unsigned row_mul; // (8 * row_slots) << 20: __umulhi(code << kRowShift, row_mul) = the row's LDS byte offset
+    int* tile_arrivals;   // [ntiles], zero between searches: chunk workgroups of a tile that have published their counts
     // single-chunk searches finish here: score bounds per offset, running best pessimistic
     // bound (atomic max), candidates = offsets whose optimistic bound reaches it.  The counts do
     // not depend on the search mode, so one pass can select for several modes (MAX and MIN of the
     // same weights): one CountSelect each.
-    int inline_select;                // 0: write `partial`, psa_keys_kernel + psa_select_kernel follow
+    int inline_select;                // 0: only write the raw per-chunk counts to `partial` (psa_debug_counts)
     int nmodes;                       // 1 or 2
     int cap;
     int first;                        // first offset of the searched range
@@ -337,6 +340,10 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     const int tile_o0 = a.base + blockIdx.x * kTile;           // absolute offset of word 0, bit 0 (multiple of 32)
     const int chunk_c0 = blockIdx.y * a.chunk_chars;           // first char of this chunk (multiple of 32)
     const int slot0 = (tile_o0 + chunk_c0) >> 5;               // first staged slot
+    // rows are 4 KiB apart in the 16-wave kernel (a Seq2 symbol, stored as code << 12, is its row's byte
+    // offset); smaller workgroups pack them (two workgroups per CU) and rescale the symbol on the scalar unit
+    const int row_slots = WAVES == 16 ? kRowSlots : a.row_slots;
+    auto row_of = [&](unsigned sym) -> unsigned { return WAVES == 16 ? sym : __umulhi(sym, a.row_mul); };
 
     // Build the class planes of the window [tile_o0+chunk_c0, +kTile+chunk_chars) in LDS: row b
     // (Seq2 symbol), slot s holds {lo, hi}: bit t of lo = class(Seq1[32*(slot0+s)+t], b) in
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
             for (int t = 0; t < 32; ++t) v[t] = tab[(w[t >> 2] >> (8 * (t & 3))) & 0xffu];
             transpose32(v);
 #pragma unroll
-            for (int b = 0; b < kMaskRows; ++b) dst[(b * kRowSlots + slot) * 2] = v[b];
+            for (int b = 0; b < kMaskRows; ++b) dst[(b * row_slots + slot) * 2] = v[b];
             slot = next;
         }
     }
@@ -395,13 +402,13 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     // the last prefetches of a wave run past its range into valid padding and are never used
     unsigned rowoff[kUnroll], rowoff_next[kUnroll];
 #pragma unroll
-    for (int q = 0; q < kUnroll; ++q) rowoff[q] = off32[q];
+    for (int q = 0; q < kUnroll; ++q) rowoff[q] = row_of(off32[q]);
     SlotRegs cur;
     lds_issue(cur, lane_addr + rowoff[0]);
     lds_retire(cur);
     for (int g = 0; g < a.wave_chars; g += kUnroll) {
 #pragma unroll
-        for (int q = 0; q < kUnroll; ++q) rowoff_next[q] = off32[g + kUnroll + q];   // wave-uniform
+        for (int q = 0; q < kUnroll; ++q) rowoff_next[q] = row_of(off32[g + kUnroll + q]);   // wave-uniform
         count_round(cnt, cur, rowoff, rowoff_next[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
 #pragma unroll
         for (int q = 0; q < kUnroll; ++q) rowoff[q] = rowoff_next[q];
@@ -496,14 +503,44 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
             for (int e = 0; e < kPer; ++e) n[k][e] |= ((v >> e) & 1u) << p;
         }
     }
-    if (!a.inline_select) {
+    if (!a.inline_select || gridDim.y > 1) {
         unsigned long long* dst = a.partial + (size_t)blockIdx.y * a.span_pad + (size_t)blockIdx.x * kTile + o_local;
 #pragma unroll
         for (int e = 0; e < kPer; ++e)
-            dst[e] = (unsigned long long)n[0][e] | ((unsigned long long)n[1][e] << 21) | ((unsigned long long)n[2][e] << 42);
-        return;
+            __builtin_nontemporal_store((unsigned long long)n[0][e] | ((unsigned long long)n[1][e] << 21) |
+                                        ((unsigned long long)n[2][e] << 42), dst + e);
+        if (!a.inline_select) return;
+        // Several char chunks per tile: the last chunk workgroup of the tile to arrive adds the others'
+        // counts to its own and goes on alone.  The chunk workgroups may sit on different XCDs (separate
+        // L2s): every wave waits for its stores, ONE thread does the agent-scope release (an L2 write-back,
+        // expensive per call) and the arrival; the counts are read back with agent-scope loads.
+        __shared__ int s_last_chunk;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const int arrived = __hip_atomic_fetch_add(a.tile_arrivals + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last_chunk = arrived == (int)gridDim.y - 1;
+            if (s_last_chunk) {
+                __hip_atomic_store(a.tile_arrivals + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+        }
+        __syncthreads();
+        if (!s_last_chunk) return;
+        for (int c = 0; c < (int)gridDim.y; ++c) {
+            if (c == (int)blockIdx.y) continue;
+            const unsigned long long* src = a.partial + (size_t)c * a.span_pad + (size_t)blockIdx.x * kTile + o_local;
+#pragma unroll
+            for (int e = 0; e < kPer; ++e) {
+                const unsigned long long v = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                n[0][e] += (unsigned)(v & 0x1fffffu);
+                n[1][e] += (unsigned)((v >> 21) & 0x1fffffu);
+                n[2][e] += (unsigned)((v >> 42) & 0x1fffffu);
+            }
+        }
     }
-    // one chunk: the counts are final
+    // the counts are final
     PSA_PHASE(5);
     unsigned long long* s_best = reinterpret_cast<unsigned long long*>(scratch);
     for (int mode = 0; mode < a.nmodes; ++mode) {
@@ -549,84 +586,6 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
             }
     }
     PSA_PHASE(6);
-}
-
-// ---- keys (searches with several char chunks): counts -> score interval per offset
-struct KeyArgs {
-    const unsigned long long* partial;   // [nchunks][span_pad]
-    double*                   upper;     // [span]: optimistic score of every offset
-    unsigned long long*       block_best;  // [gridDim.x]: ordered-u64 of each block's best pessimistic score
-    BoundParams bounds;
-    int nchunks;
-    int span_pad;
-    int span;
-    int lead;         // offsets of tile 0 in front of the range (first - base)
-};
-
-constexpr int kKeyBlocks = 1024;   // grid of the keys / select kernels (grid-stride over the offsets)
-
-__global__ __launch_bounds__(256) void psa_keys_kernel(KeyArgs a)
-{
-    __shared__ unsigned long long s_best[4];
-    double pess = -INFINITY;
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < a.span; o += gridDim.x * 256) {
-        unsigned long long sum = 0ull;
-        for (int c = 0; c < a.nchunks; ++c) sum += a.partial[(size_t)c * a.span_pad + a.lead + o];
-        double up, pe;
-        offset_bounds(a.bounds, (int)(sum & 0x1fffff), (int)((sum >> 21) & 0x1fffff), (int)((sum >> 42) & 0x1fffff), up, pe);
-        a.upper[o] = up;
-        pess = fmax(pess, pe);
-    }
-    unsigned long long key = order_key(pess);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long other = __shfl_xor(key, d, 64);
-        key = other > key ? other : key;
-    }
-    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = key;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) key = s_best[w] > key ? s_best[w] : key;
-        a.block_best[blockIdx.x] = key;
-    }
-}
-
-// ---- select: offsets whose optimistic score reaches the best pessimistic one ----
-struct SelectArgs {
-    const double*             upper;
-    const unsigned long long* block_best;   // [nbest] from the keys kernel
-    int*                      cand;         // [cap]
-    int*                      cand_count;
-    int nbest;
-    int span;
-    int first;
-    int cap;
-};
-
-__global__ __launch_bounds__(256) void psa_select_kernel(SelectArgs a)
-{
-    __shared__ unsigned long long s_best[4];
-    unsigned long long key = 0ull;
-    for (int k = threadIdx.x; k < a.nbest; k += 256) {
-        const unsigned long long v = a.block_best[k];
-        key = v > key ? v : key;
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long other = __shfl_xor(key, d, 64);
-        key = other > key ? other : key;
-    }
-    if ((threadIdx.x & 63) == 0) s_best[threadIdx.x >> 6] = key;
-    __syncthreads();
-    key = s_best[0];
-    for (int w = 1; w < 4; ++w) key = s_best[w] > key ? s_best[w] : key;
-    const double need = key_order(key);
-    for (int o = blockIdx.x * 256 + threadIdx.x; o < a.span; o += gridDim.x * 256) {
-        if (a.upper[o] >= need) {
-            const int slot = atomicAdd(a.cand_count, 1);
-            if (slot < a.cap) a.cand[slot] = a.first + o;
-        }
-    }
 }
 
 // ---- rescore: the reference's sequential fp64 sum for each candidate -----------

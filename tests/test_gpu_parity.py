@@ -585,7 +585,9 @@ def test_drop_in_program_pretty_view(psa, oracle, reference_records, tmp_path):
 
 def test_long_seq2_multi_chunk_path(psa, oracle):
     """|Seq2| above one workgroup's reach (16 waves x 992 chars): several char chunks, partial counts
-    combined by psa_keys_kernel / psa_select_kernel; also a short range that spreads chunks to fill the GPU."""
+    whose
+    workgroups combine their partial counts inside the count kernel (last arriver per tile); also a short range
+    that spreads chunks to fill the GPU."""
     s1 = psa.generate_sequence(91, 60000)
     s2 = psa.generate_sequence(92, 20011)
     for is_max in (True, False):
