@@ -254,6 +254,22 @@ def main():
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(kernel_name)
 
+    # Calibration of the achievable HBM bandwidth on this GPU: device-to-device copy of 1 GiB,
+    # read + write counted.  Beside it, the kernel's MEASURED HBM rate = PMC traffic per launch / duration.
+    copy_gbs = None
+    if rank == 0:
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=device)
+        dst = torch.empty_like(src)
+        dst.copy_(src)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dst.copy_(src)
+        e1.record()
+        torch.cuda.synchronize(device)
+        copy_gbs = 10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
+
     q0 = results[0] if (args.mode == "shard" or world > 1 or qlo == 0) else one
     line = {
         "metric": "char-pair scores/sec (whole job), |Seq1|=1M |Seq2|=10k MAX searches",
@@ -280,6 +296,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "kernel": kernel_name, "kernel_ms": 1e3 * kernel_s,
+                     "measured_hbm_GBps": (traffic / kernel_s / 1e9) if traffic else None,
+                     "hbm_copy_calibration_GBps": copy_gbs,
                      "algorithmic_bytes_per_launch": BYTES_PER_PAIR * pairs_launch,
                      "note": "algorithmic bytes = 2 B per char pair (SURVEY.md 8d); tiles are reused from "
                              "LDS/L2 so physical HBM traffic is a few MB per search (frac > 1 is expected: "

@@ -258,6 +258,37 @@ def test_full_size_properties(ctx, oracle, psa):
         assert s > res.score or (s == res.score and o >= res.offset)
 
 
+def test_beyond_one_wave_of_workgroups(psa, oracle):
+    """|Seq1| = 5M (beyond the reference's and BASELINE's sizes): 1221 tiles on 256 CUs, so the count kernel's
+    grid runs in several rounds.  Filter and sequential engines (independent kernels) agree bit for bit in both
+    modes and on a sub-range, a planted copy is found, and the winners re-derive on the oracle."""
+    n, m = 5_000_000, 2_000
+    s1 = bytearray(psa.generate_sequence(3001, n))
+    s2 = psa.generate_sequence(3002, m)
+    plant = 4_321_987
+    s1[plant:plant + m] = s2
+    s1 = bytes(s1)
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    with psa.Context(0) as cf, psa.Context(0) as cs:
+        cf.set_engine(psa.ENGINE_FILTER)
+        cs.set_engine(psa.ENGINE_SEQUENTIAL)
+        for c in (cf, cs):
+            c.set_seq1(s1)
+            c.set_seq2(s2)
+        for is_max in (True, False):
+            for c in (cf, cs):
+                c.set_weights(W_README, is_max)
+            a, b = cf.search(), cs.search()
+            assert key(a) == key(b)
+            if is_max:
+                assert a.offset == plant
+            want_score, want_ci, want_ch = oracle.score_offset(s1, s2, W_README, is_max, a.offset)
+            assert (a.score, a.char_offset, chr(a.ch)) == (want_score, want_ci, want_ch)
+            lo, hi = 1_000_003, 4_000_001
+            assert key(cf.search(lo, hi)) == key(cs.search(lo, hi))
+        assert cf.fallback_count() == 0
+
+
 # ---------------------------------------------------------------------------
 # filter engine (bit-sliced class counts -> candidates -> sequential re-score)
 # ---------------------------------------------------------------------------
