@@ -373,6 +373,12 @@ struct psa_context {
     hipStream_t twin = nullptr;        // owned: every other count kernel of a pooled batch (kernels overlap at their edges)
     int batch_streams = 2;
     int batch_rescore_grid = 8;        // re-score workgroups per query inside a batch (the CUs are busy counting)
+    int granted16 = 0, granted8 = 0;   // dynamic-LDS grants of the count kernels on this context's device
+    bool granted_duo = false;
+    bool duo = true;                   // batches: one workgroup per tile serves several queries (psa_count_duo_kernel)
+    int  duo_queries = 32;             // queries per launch of it
+    int  duo_skew_ticks = 1300;        // 100 MHz ticks group 1 starts late (one epilogue)
+    bool granted_rescore = false;
     bool rescore_pad = true;
     bool        own_stream = false;
 
@@ -518,6 +524,10 @@ psa_status report_bad(psa_context* c)
     if (!bad) return PSA_OK;
     PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
     *c->h_bad = 0;
+    if (bad & 4) {
+        set_last_error("internal: a wave-group barrier of the batch count kernel timed out");
+        return PSA_ERR_DEVICE;
+    }
     if (bad & 1) c->n = -1;
     if (bad & 2) for (auto& s : c->slot) s.m = -1;
     set_last_error(std::string(bad & 1 ? "seq1" : "seq2") + " contains a character outside [A-Z-]");
@@ -793,25 +803,77 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
         a.sel[1].bounds = bound_params(*ts2->t, s.m);
     }
     const dim3 grid(p.ntiles, p.nchunks);
-    // dynamic LDS above 64 KB has to be granted per kernel; remember the largest grant
-    static int granted16 = 0, granted8 = 0;
+    // dynamic LDS above 64 KB has to be granted per kernel (and device: the flags live in the context)
     if (p.waves == 16) {
-        if (p.lds_bytes > granted16) {
+        if (p.lds_bytes > c->granted16) {
             PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
-            granted16 = kLdsLimit;
+            c->granted16 = kLdsLimit;
         }
         hipLaunchKernelGGL(psa::psa_count_kernel<16>, grid, dim3(16 * 64), p.lds_bytes, stream, a);
         c->last_kernel = "psa_count_kernel<16>";
     } else {
-        if (p.lds_bytes > granted8) {
+        if (p.lds_bytes > c->granted8) {
             PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<8>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
-            granted8 = kLdsLimit;
+            c->granted8 = kLdsLimit;
         }
         hipLaunchKernelGGL(psa::psa_count_kernel<8>, grid, dim3(8 * 64), p.lds_bytes, stream, a);
         c->last_kernel = "psa_count_kernel<8>";
     }
+    PSA_HIP(hipGetLastError());
+    return PSA_OK;
+}
+
+// Batches: queries [q, q+count) of a pooled batch through psa_count_duo_kernel.  `scal`, `cand`, `cand_upper`
+// are the pool entries of query q in each mode.
+bool duo_fits(int m, int* wave_chars, int* lds_slots)
+{
+    int wc = (m + psa::kDuoGroupWaves - 1) / psa::kDuoGroupWaves;
+    wc = (wc + psa::kUnroll - 1) / psa::kUnroll * psa::kUnroll;
+    const int slots = psa::kDuoGroupWaves * wc / 32 + 129;
+    if (wc > psa::kDuoMaxWaveChars || slots > psa::kRowSlots || psa::kDuoLdsBytes > kLdsLimit) return false;
+    *wave_chars = wc;
+    *lds_slots = slots;
+    return true;
+}
+
+psa_status launch_count_duo(psa_context* c, const unsigned* s2rows, size_t s2_stride, int m, int count, int first, int last,
+                            int nmodes, const TableSet* tables, Scalars* const scal[2], int* const cand[2],
+                            double* const cand_upper[2], hipStream_t stream)
+{
+    static_assert(sizeof(Scalars) == psa::kScalStride && offsetof(Scalars, cand_count) == psa::kScalCountOffset,
+                  "psa_count_duo_kernel addresses the pool scalars by these strides");
+    psa::DuoArgs a;
+    if (!duo_fits(m, &a.wave_chars, &a.lds_slots)) { set_last_error("internal: duo kernel does not fit"); return PSA_ERR_ARG; }
+    const int base = first & ~31;
+    a.s1 = c->d_s1;
+    a.symbol_planes = c->d_symbol_planes;
+    a.s2off = s2rows;
+    a.s2_stride = s2_stride;
+    a.base = base;
+    a.nq = count;
+    a.nmodes = nmodes;
+    a.cap = kCandCap;
+    a.first = first;
+    a.lead = first - base;
+    a.span = last - first;
+    a.skew_ticks = (unsigned)c->duo_skew_ticks;
+    a.bad = c->d_bad;
+    for (int k = 0; k < 2; ++k) {
+        const int src = k < nmodes ? k : 0;
+        a.sel[k].scalars = reinterpret_cast<char*>(scal[src]);
+        a.sel[k].cand = cand[src];
+        a.sel[k].cand_upper = cand_upper[src];
+        a.sel[k].bounds = bound_params(*tables[src].t, m);
+    }
+    if (!c->granted_duo) {
+        PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_duo_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, psa::kDuoLdsBytes));
+        c->granted_duo = true;
+    }
+    const int ntiles = (last - base + psa::kTile - 1) / psa::kTile;
+    hipLaunchKernelGGL(psa::psa_count_duo_kernel, dim3(ntiles), dim3(1024), psa::kDuoLdsBytes, stream, a);
     PSA_HIP(hipGetLastError());
     return PSA_OK;
 }
@@ -862,8 +924,9 @@ psa_status launch_filter_front(psa_context* c, SearchSlot& s, const FilterPlan& 
 }
 
 // exact re-score of the candidates + fold into the slot's tail
+// `batch` > 0: s describes the first of `batch` consecutive pool entries (queries) re-scored by one launch
 psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hipStream_t stream, const TableSet& ts,
-                              int grid = psa::kRescoreGrid)
+                              int grid = psa::kRescoreGrid, int batch = 0, size_t s2_stride = 0)
 {
     const psa::Tables& t = *ts.t;
     psa::RescoreArgs r;
@@ -906,13 +969,14 @@ psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hi
         r.fast_ok = ok && !chain_only;
         r.fast_min_exp = max_exp + 2;
     }
-    static bool granted = false;
-    if (!granted) {
+    if (!c->granted_rescore) {
         PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_rescore_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, psa::kRescorePadLds));
-        granted = true;
+        c->granted_rescore = true;
     }
-    hipLaunchKernelGGL(psa::psa_rescore_kernel, dim3(grid), dim3(psa::kRescoreThreads),
+    r.batched = batch > 0 ? 1 : 0;
+    r.s2_stride = s2_stride;
+    hipLaunchKernelGGL(psa::psa_rescore_kernel, dim3(grid, batch > 0 ? batch : 1), dim3(psa::kRescoreThreads),
                        c->rescore_pad ? psa::kRescorePadLds : 0, stream, r);
     PSA_HIP(hipGetLastError());
     return PSA_OK;
@@ -1051,6 +1115,9 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     if (const char* r = std::getenv("PSA_BATCH_STREAMS")) c->batch_streams = std::atoi(r) >= 2 ? 2 : 1;
     if (const char* r = std::getenv("PSA_RESCORE_GRID")) c->batch_rescore_grid = std::max(1, std::min(1024, std::atoi(r)));
     if (const char* r = std::getenv("PSA_RESCORE_PAD")) c->rescore_pad = std::atoi(r) != 0;
+    if (const char* r = std::getenv("PSA_DUO")) c->duo = std::atoi(r) != 0;
+    if (const char* r = std::getenv("PSA_DUO_QUERIES")) c->duo_queries = std::max(2, std::min(4096, std::atoi(r)));
+    if (const char* r = std::getenv("PSA_DUO_SKEW")) c->duo_skew_ticks = std::max(0, std::atoi(r));
     *out = c;
     return PSA_OK;
 }
@@ -1100,6 +1167,10 @@ void psa_destroy(psa_context* c)
 psa_status psa_set_weights(psa_context* c, const double weights[4], int is_max)
 {
     if (!c || !weights) { set_last_error("psa_set_weights: NULL argument"); return PSA_ERR_ARG; }
+    // the same weights (bit for bit) and mode as last time: the tables on the device are current
+    if (c->have_weights && (c->tables.is_max != 0) == (is_max != 0) &&
+        std::memcmp(c->tables.weights, weights, sizeof(double) * 4) == 0)
+        return PSA_OK;
     std::string err;
     psa::Tables t;
     if (!psa::build_tables(weights, is_max, &t, &err)) { set_last_error(err); return PSA_ERR_ARG; }
@@ -1308,7 +1379,39 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
         v.d_arrivals = c->d_ring_arrivals[q & 1];
         return v;
     };
-    if (pooled) {
+    int duo_wc = 0, duo_slots = 0;
+    const bool duo = pooled && c->duo && nq >= 2 && plan.nchunks == 1 && plan.waves == 16 && duo_fits(m, &duo_wc, &duo_slots);
+    if (duo) {
+        // several queries per count launch (two wave groups per tile share the planes and alternate between
+        // main loop and epilogue); launches alternate between the two streams, the re-scores follow on the third
+        int launch = 0;
+        for (int q0 = 0; q0 < nq; q0 += c->duo_queries, ++launch) {
+            const int count = std::min(c->duo_queries, nq - q0);
+            hipStream_t front = twin && (launch & 1) ? c->twin : c->stream;
+            Scalars* scal[2];
+            int* cand[2];
+            double* cand_upper[2];
+            for (int mode = 0; mode < 2; ++mode) {
+                const size_t e = (size_t)(mode < nmodes ? mode : 0) * nq + q0;
+                scal[mode] = c->d_pool_scal + e;
+                cand[mode] = c->d_pool_cand + e * kCandCap;
+                cand_upper[mode] = c->d_pool_cand_upper + e * kCandCap;
+            }
+            PSA_TRY(launch_count_duo(c, c->d_batch_rows + (size_t)q0 * ostride, (size_t)ostride, m, count, first, last,
+                                     nmodes, tables, scal, cand, cand_upper, front));
+            hipEvent_t done = c->pool_events[q0];
+            PSA_HIP(hipEventRecord(done, front));
+            PSA_HIP(hipStreamWaitEvent(c->aux, done, 0));
+            // one re-score launch per mode for the whole group of queries (grid.y = query)
+            c->seq = seq0 + q0;
+            for (int mode = 0; mode < nmodes; ++mode) {
+                SearchSlot s = pool_view(mode, q0);
+                s.inline_select = true;
+                PSA_TRY(launch_filter_back(c, s, pairs, c->aux, tables[mode], c->batch_rescore_grid, count, (size_t)ostride));
+            }
+            c->seq = seq0 + q0 + count - 1;
+        }
+    } else if (pooled) {
         for (int q = 0; q < nq; ++q) {
             hipStream_t front = twin && (q & 1) ? c->twin : c->stream;
             SearchSlot s0 = pool_view(0, q);

@@ -60,14 +60,15 @@ __device__ __forceinline__ unsigned csa(unsigned& a, unsigned b, unsigned c)
 // One bit-sliced counter: planes[p] holds bit p of 32 independent counts.
 // Values are pushed one per char; level L keeps one pending input so that
 // every second arrival triggers a full adder whose carry moves up a level.
-struct SlicedCounter {
-    unsigned plane[kPlanes];
+template <int PLANES>
+struct SlicedCounterT {
+    unsigned plane[PLANES];
     unsigned pend[kLevels];
 
     __device__ __forceinline__ void clear()
     {
 #pragma unroll
-        for (int p = 0; p < kPlanes; ++p) plane[p] = 0u;
+        for (int p = 0; p < PLANES; ++p) plane[p] = 0u;
     }
 
     // T = index of the char inside the round, L = level (both compile-time so the
@@ -78,12 +79,12 @@ struct SlicedCounter {
         if constexpr (L == kLevels) {
             // one carry of weight 2^kLevels per round: ripple into the upper planes
 #pragma unroll
-            for (int p = kLevels; p < kPlanes - 1; ++p) {
+            for (int p = kLevels; p < PLANES - 1; ++p) {
                 const unsigned c = plane[p] & v;
                 plane[p] ^= v;
                 v = c;
             }
-            plane[kPlanes - 1] ^= v;
+            plane[PLANES - 1] ^= v;
         } else if constexpr ((T & 1) == 0) {
             pend[L] = v;
         } else {
@@ -94,6 +95,7 @@ struct SlicedCounter {
     template <int T>
     __device__ __forceinline__ void push(unsigned v) { push_level<0, T>(v); }
 };
+using SlicedCounter = SlicedCounterT<kPlanes>;
 
 // ---- Seq2 queries of a batch: ASCII -> codes, all queries in one launch -------
 __global__ __launch_bounds__(256) void psa_encode_batch_kernel(const unsigned char* __restrict__ raw, int nq, int m,
@@ -209,8 +211,8 @@ __device__ __forceinline__ void lds_retire(SlotRegs& n)
 // slot column.  Lane l owns words l and l+64 of the tile: consecutive lanes read
 // consecutive 8-byte slots (conflict-free).  `cur` holds this char's slots; the
 // next char's are requested first (J == 31: char 0 of the next round, one column on).
-template <int J>
-__device__ __forceinline__ void count_step(SlicedCounter (&cnt)[2][kCounters], SlotRegs& cur,
+template <int J, typename Counter>
+__device__ __forceinline__ void count_step(Counter (&cnt)[2][kCounters], SlotRegs& cur,
                                            const unsigned (&rowoff)[kUnroll], unsigned next_rowoff,
                                            unsigned lane_addr)
 {
@@ -237,8 +239,8 @@ __device__ __forceinline__ void count_step(SlicedCounter (&cnt)[2][kCounters], S
     cur = nxt;
 }
 
-template <int... Js>
-__device__ __forceinline__ void count_round(SlicedCounter (&cnt)[2][kCounters], SlotRegs& cur,
+template <typename Counter, int... Js>
+__device__ __forceinline__ void count_round(Counter (&cnt)[2][kCounters], SlotRegs& cur,
                                             const unsigned (&rowoff)[kUnroll], unsigned next_rowoff,
                                             unsigned lane_addr, std::integer_sequence<int, Js...>)
 {
@@ -588,6 +590,278 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     PSA_PHASE(6);
 }
 
+// ---- duo count kernel (batches) ------------------------------------------------
+// One workgroup per tile handles SEVERAL queries of a batch.  The tile's class planes depend on
+// Seq1 only: they are built once and shared by two groups of 8 waves.  Group g takes queries
+// g, g+2, ...: main loop over all chars of its query (8 waves x wave_chars), then its own epilogue
+// (merge, expand, bounds, candidates) in its own scratch, synchronised by a group-local barrier (an
+// LDS counter; s_barrier would stop the other group too).  Group 1 starts one epilogue late, so
+// while one group runs the latency-bound epilogue the other keeps the VALUs busy with its main
+// loop — in psa_count_kernel those phases (about 15 % of the kernel) leave the CU idle.
+constexpr int kDuoGroupWaves = 8;
+constexpr int kDuoPlanes = 11;             // per-wave counters: up to 2047 chars
+constexpr int kDuoMaxWaveChars = 2016;     // multiple of kUnroll below 2^kDuoPlanes
+constexpr int kDuoMergedPlanes = 14;       // 8 x 2047 < 2^14
+constexpr int kDuoPer = kTile / (kDuoGroupWaves * 64);     // offsets expanded per thread
+// per group: round 0 of one counter's merge (4 writers x 2 words x 11 planes x 64 lanes) >= the published planes
+constexpr int kDuoScratchBytes = 4 * 2 * kDuoPlanes * 64 * 4;
+static_assert(kCounters * kDuoMergedPlanes * 128 * 4 <= kDuoScratchBytes, "published planes fit the group scratch");
+constexpr int kDuoLdsBytes = kMaskRows * kRowSlots * 8 + 2 * kDuoScratchBytes;
+constexpr int kScalStride = 16;            // bytes between the search scalars of consecutive queries (host: Scalars)
+constexpr int kScalCountOffset = 8;        // cand_count inside them
+
+struct DuoArgs {
+    const unsigned char* s1;
+    const unsigned*      symbol_planes;
+    const unsigned*      s2off;        // symbols of the launch's first query; query q at + q * s2_stride
+    size_t               s2_stride;    // in elements
+    int base;             // first offset of tile 0 (multiple of 32)
+    int wave_chars;       // chars per wave (multiple of kUnroll, <= kDuoMaxWaveChars); 8 waves cover the query
+    int lds_slots;        // slots per staged row
+    int nq;               // queries of this launch
+    int nmodes;
+    int cap;
+    int first, lead, span;
+    unsigned skew_ticks;  // 100 MHz ticks group 1 waits before its first query
+    int* bad;             // |= 4 if a group barrier timed out (never expected)
+    struct Select {
+        char*   scalars;      // search scalars of the launch's first query (kScalStride apart)
+        int*    cand;         // candidate offsets, `cap` per query
+        double* cand_upper;
+        BoundParams bounds;
+    } sel[2];
+};
+
+// barrier of the 8 waves of one group: arrival counter in LDS, monotonic (target grows by 8 per barrier)
+__device__ __forceinline__ void duo_barrier(unsigned* ctr, unsigned& target, int lane, int* bad)
+{
+    target += (unsigned)kDuoGroupWaves;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // this wave's LDS traffic is complete
+    if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    int spins = 0;
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1 << 21)) {                                   // ~0.1 s: give up loudly instead of hanging
+            if (lane == 0) atomicOr(bad, 4);
+            break;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
+__global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
+{
+    extern __shared__ uint2 lds[];                  // [kMaskRows][kRowSlots] planes, then one scratch per group
+    __shared__ unsigned s_planes[64];
+    __shared__ unsigned s_bar[2];
+    __shared__ unsigned long long s_best[2][kDuoGroupWaves + 1];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int group = wave >> 3;
+    const int gw = wave & 7;                         // wave inside its group
+    const int gtid = tid & (kDuoGroupWaves * 64 - 1);
+    const int tile_o0 = a.base + blockIdx.x * kTile;
+    const int slot0 = tile_o0 >> 5;
+
+    // ---- planes of the window [tile_o0, +kTile+m): as psa_count_kernel<16>
+    {
+        constexpr int kHalf = 512;
+        const int hi_half = tid >= kHalf ? 1 : 0;
+        int slot = tid - kHalf * hi_half;
+        const uint4* src = reinterpret_cast<const uint4*>(a.s1 + ((size_t)slot0 << 5));
+        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+        if (slot < a.lds_slots) { c0 = src[2 * slot]; c1 = src[2 * slot + 1]; }
+        if (tid < 64) s_planes[tid] = a.symbol_planes[tid];
+        if (tid < 2) s_bar[tid] = 0u;
+        __syncthreads();
+        const unsigned* tab = s_planes + 32 * hi_half;
+        unsigned* dst = reinterpret_cast<unsigned*>(lds) + hi_half;
+        while (slot < a.lds_slots) {
+            const unsigned w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            const int next = slot + kHalf;
+            if (next < a.lds_slots) { c0 = src[2 * next]; c1 = src[2 * next + 1]; }
+            unsigned v[32];
+#pragma unroll
+            for (int t = 0; t < 32; ++t) v[t] = tab[(w[t >> 2] >> (8 * (t & 3))) & 0xffu];
+            transpose32(v);
+#pragma unroll
+            for (int b = 0; b < kMaskRows; ++b) dst[(b * kRowSlots + slot) * 2] = v[b];
+            slot = next;
+        }
+    }
+    __syncthreads();                                 // the last workgroup-wide barrier: the groups part here
+
+    unsigned* const scratch = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + kMaskRows * kRowSlots * 8 +
+                                                          group * kDuoScratchBytes);
+    unsigned* const bar = &s_bar[group];
+    unsigned bar_target = 0u;
+    if (group == 1 && a.nq > 1) {
+        const unsigned long long t0 = wall_clock64();
+        while (wall_clock64() - t0 < a.skew_ticks) __builtin_amdgcn_s_sleep(8);
+    }
+    using const_u32 = const __attribute__((address_space(4))) unsigned;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds;
+
+#ifdef PSA_PHASE_TIMING
+#define PSA_DPHASE(k) do { if (gtid == 0 && blockIdx.x == 7 && (q >> 1) < 16) g_phase_ts[600 + group * 16 + (q >> 1)][k] = wall_clock64(); } while (0)
+#else
+#define PSA_DPHASE(k) do { } while (0)
+#endif
+    for (int q = group; q < a.nq; q += 2) {
+        PSA_DPHASE(0);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- main loop: this wave's chars of query q against the whole tile
+        SlicedCounterT<kDuoPlanes> cnt[2][kCounters];
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int k = 0; k < kCounters; ++k) cnt[w][k].clear();
+        const int c_begin = gw * a.wave_chars;
+        const_u32* off32 = (const_u32*)(size_t)(a.s2off + (size_t)q * a.s2_stride + c_begin);
+        unsigned lane_addr = lds_base + (unsigned)lane * 8u + (unsigned)(c_begin >> 5) * 8u;
+        unsigned rowoff[kUnroll], rowoff_next[kUnroll];
+#pragma unroll
+        for (int i = 0; i < kUnroll; ++i) rowoff[i] = off32[i];
+        SlotRegs cur;
+        lds_issue(cur, lane_addr + rowoff[0]);
+        lds_retire(cur);
+        for (int g = 0; g < a.wave_chars; g += kUnroll) {
+#pragma unroll
+            for (int i = 0; i < kUnroll; ++i) rowoff_next[i] = off32[g + kUnroll + i];
+            count_round(cnt, cur, rowoff, rowoff_next[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
+#pragma unroll
+            for (int i = 0; i < kUnroll; ++i) rowoff[i] = rowoff_next[i];
+            lane_addr += 8u;
+        }
+
+        PSA_DPHASE(1);
+        // the epilogue is a chain of short, latency-bound steps: let its instructions pass the other group's main loop
+        __builtin_amdgcn_s_setprio(3);
+        // ---- merge the group's 8 partial counters, one counter per pass (the scratch holds one)
+        unsigned merged[2][kCounters][kDuoMergedPlanes];
+#pragma unroll
+        for (int w = 0; w < 2; ++w)
+#pragma unroll
+            for (int k = 0; k < kCounters; ++k)
+#pragma unroll
+                for (int p = 0; p < kDuoMergedPlanes; ++p) merged[w][k][p] = p < kDuoPlanes ? cnt[w][k].plane[p] : 0u;
+#pragma unroll
+        for (int k = 0; k < kCounters; ++k) {
+            int r = 0;
+#pragma unroll
+            for (int half = kDuoGroupWaves / 2; half >= 1; half >>= 1, ++r) {
+                const int np = kDuoPlanes + r;
+                const int rec = 2 * np;
+                if (gw >= half && gw < 2 * half) {
+                    unsigned* dst = scratch + (size_t)(gw - half) * rec * 64 + lane;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w)
+#pragma unroll
+                        for (int p = 0; p < kDuoMergedPlanes; ++p)
+                            if (p < np) dst[(w * np + p) * 64] = merged[w][k][p];
+                }
+                duo_barrier(bar, bar_target, lane, a.bad);
+                if (gw < half) {
+                    const unsigned* src = scratch + (size_t)gw * rec * 64 + lane;
+#pragma unroll
+                    for (int w = 0; w < 2; ++w) {
+                        unsigned carry = 0u;
+#pragma unroll
+                        for (int p = 0; p < kDuoMergedPlanes; ++p)
+                            if (p < np) {
+                                const unsigned other = src[(w * np + p) * 64];
+                                const unsigned x = merged[w][k][p];
+                                merged[w][k][p] = xor3(x, other, carry);
+                                carry = maj3(x, other, carry);
+                            } else if (p == np) {
+                                merged[w][k][p] = carry;
+                            }
+                    }
+                }
+                duo_barrier(bar, bar_target, lane, a.bad);
+            }
+        }
+        PSA_DPHASE(2);
+        // wave 0 of the group publishes the merged planes: [counter][plane][word(128)]
+        if (gw == 0) {
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+#pragma unroll
+                for (int k = 0; k < kCounters; ++k)
+#pragma unroll
+                    for (int p = 0; p < kDuoMergedPlanes; ++p)
+                        scratch[(k * kDuoMergedPlanes + p) * 128 + w * 64 + lane] = merged[w][k][p];
+        }
+        duo_barrier(bar, bar_target, lane, a.bad);
+
+        // ---- expand: kDuoPer consecutive offsets of one word per thread
+        const int o_local = gtid * kDuoPer;
+        const int word = o_local >> 5;
+        const int bit0 = o_local & 31;
+        unsigned n[kCounters][kDuoPer];
+#pragma unroll
+        for (int k = 0; k < kCounters; ++k) {
+#pragma unroll
+            for (int e = 0; e < kDuoPer; ++e) n[k][e] = 0u;
+#pragma unroll
+            for (int p = 0; p < kDuoMergedPlanes; ++p) {
+                const unsigned v = scratch[(k * kDuoMergedPlanes + p) * 128 + word] >> bit0;
+#pragma unroll
+                for (int e = 0; e < kDuoPer; ++e) n[k][e] |= ((v >> e) & 1u) << p;
+            }
+        }
+        PSA_DPHASE(3);
+        // ---- bounds, running best, candidates (per mode), as psa_count_kernel
+        for (int mode = 0; mode < a.nmodes; ++mode) {
+            const DuoArgs::Select& sel = a.sel[mode];
+            unsigned long long* global_best = reinterpret_cast<unsigned long long*>(sel.scalars + (size_t)q * kScalStride);
+            int* cand_count = reinterpret_cast<int*>(sel.scalars + (size_t)q * kScalStride + kScalCountOffset);
+            int* cand = sel.cand + (size_t)q * a.cap;
+            double* cand_upper = sel.cand_upper + (size_t)q * a.cap;
+            double up[kDuoPer];
+            double pess = -INFINITY;
+#pragma unroll
+            for (int e = 0; e < kDuoPer; ++e) {
+                const int o = (int)blockIdx.x * kTile + o_local + e - a.lead;
+                up[e] = -INFINITY;
+                if (o >= 0 && o < a.span) {
+                    double pe;
+                    offset_bounds(sel.bounds, (int)n[0][e], (int)n[1][e], (int)n[2][e], up[e], pe);
+                    pess = fmax(pess, pe);
+                }
+            }
+            unsigned long long key = order_key(pess);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(key, d, 64);
+                key = other > key ? other : key;
+            }
+            duo_barrier(bar, bar_target, lane, a.bad);          // the previous mode's s_best has been read
+            if (lane == 0) s_best[group][gw] = key;
+            duo_barrier(bar, bar_target, lane, a.bad);
+            if (gtid == 0) {
+                for (int w = 1; w < kDuoGroupWaves; ++w) key = s_best[group][w] > key ? s_best[group][w] : key;
+                const unsigned long long old = atomicMax(global_best, key);
+                s_best[group][kDuoGroupWaves] = old > key ? old : key;
+            }
+            duo_barrier(bar, bar_target, lane, a.bad);
+            const double need = key_order(s_best[group][kDuoGroupWaves]);
+#pragma unroll
+            for (int e = 0; e < kDuoPer; ++e)
+                if (up[e] >= need) {
+                    const int slot = atomicAdd(cand_count, 1);
+                    if (slot < a.cap) {
+                        cand[slot] = a.first + (int)blockIdx.x * kTile + o_local + e - a.lead;
+                        cand_upper[slot] = up[e];
+                    }
+                }
+        }
+        duo_barrier(bar, bar_target, lane, a.bad);              // the scratch is free for the next query
+        PSA_DPHASE(4);
+    }
+}
+
 // ---- rescore: the reference's sequential fp64 sum for each candidate -----------
 // One wave per candidate.  The additions of cpu_funcs.c:278 are a serial chain of
 // m roundings, but while the running sum stays inside one binade every addend is
@@ -629,6 +903,9 @@ struct RescoreArgs {
     int is_max;
     int fast_ok;                    // all weights normal doubles or zero
     int fast_min_exp;               // smallest biased exponent of the running sum the walk handles
+    // blockIdx.y = query of a batch launch: its state lies query_stride... further on (all 0 for one search)
+    size_t s2_stride;               // bytes between the queries' codes
+    int    batched;                 // 1: cand/cand_upper/rec advance by cap, the scalars by kScalStride, out and seq by 1
 };
 
 #ifndef PSA_RESCORE_EPL
@@ -681,6 +958,18 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     __shared__ int s_last;
     extern __shared__ unsigned char s_pad[];      // never touched: only makes the workgroup too big to share a
     (void)s_pad;                                  // CU with a count-kernel workgroup (LDS), see launch site
+    if (a.batched) {
+        const size_t q = blockIdx.y;
+        a.s2 += q * a.s2_stride;
+        a.cand += q * (size_t)a.cap;
+        if (a.cand_upper) a.cand_upper += q * (size_t)a.cap;
+        a.rec += q * (size_t)a.cap;
+        a.global_best = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.global_best) + q * kScalStride);
+        a.cand_count = reinterpret_cast<int*>(reinterpret_cast<char*>(a.cand_count) + q * kScalStride);
+        a.done = reinterpret_cast<int*>(reinterpret_cast<char*>(a.done) + q * kScalStride);
+        a.out += q;
+        a.seq += (int)q;
+    }
 #ifdef PSA_PHASE_TIMING
 #define PSA_RPHASE(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_ts[1000][k] = wall_clock64(); } while (0)
 #else
