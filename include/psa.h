@@ -167,6 +167,10 @@ psa_status psa_build_tables(const double weights[4], int is_max,
  * kernel.  kernel_name may be NULL. */
 psa_status psa_set_profiling(psa_context* ctx, int on);
 psa_status psa_last_timing(psa_context* ctx, int which, float* milliseconds, const char** kernel_name);
+/* Queries covered by the kernel launch that psa_last_timing(which = 1) timed: 1 for a single
+ * search; for a batch run with profiling on, which = 0 is the whole batch and which = 1 its first
+ * count launch (one launch serves several queries). */
+int psa_last_kernel_queries(psa_context* ctx);
 /* Sums over every search completed (psa_search / psa_search_wait) since
  * profiling was switched on: whole-search ms, dominant-kernel ms, count. */
 psa_status psa_profile_totals(psa_context* ctx, double* search_ms, double* kernel_ms, int* searches);

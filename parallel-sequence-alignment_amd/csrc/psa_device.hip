@@ -437,6 +437,7 @@ struct psa_context {
     int         pending_first = 0, pending_last = 0;
     double      sum_search_ms = 0.0, sum_kernel_ms = 0.0;   // over profiled searches since profiling was switched on
     int         profiled = 0;
+    int         last_kernel_queries = 1;     // queries covered by the launch timed between ev[2] and ev[3]
     int         fallbacks = 0;               // filter searches that overflowed into the sequential engine
     int         seq = 0;                     // sequence number of the last search enqueued
 };
@@ -1233,6 +1234,7 @@ psa_status psa_search_async(psa_context* c, int first, int last)
     c->seq += 1;
     s.d_tail = c->hd_tails;
     if (c->profiling) PSA_HIP(hipEventRecord(c->ev[0], c->stream));
+    c->last_kernel_queries = 1;
     c->pending_filter = use_filter(c, first, last, s.m);
     c->pending_first = first;
     c->pending_last = last;
@@ -1322,6 +1324,8 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
     const bool filter = use_filter(c, first, last, m);
     const long long pairs = (long long)(last - first) * m;
     const int seq0 = c->seq + 1;
+    c->timing_valid = false;
+    if (c->profiling) PSA_HIP(hipEventRecord(c->ev[0], c->stream));
     // all queries encoded by one launch: [nq][ostride] codes as u32 rows and as bytes
     const int ostride = (m + kSeq2Slack + 63) & ~63;
     if ((size_t)nq * ostride > c->batch_cap) {
@@ -1397,8 +1401,15 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
                 cand[mode] = c->d_pool_cand + e * kCandCap;
                 cand_upper[mode] = c->d_pool_cand_upper + e * kCandCap;
             }
+            const bool timed = c->profiling && launch == 0;          // launch 0 runs on the main stream
+            if (timed) PSA_HIP(hipEventRecord(c->ev[2], front));
             PSA_TRY(launch_count_duo(c, c->d_batch_rows + (size_t)q0 * ostride, (size_t)ostride, m, count, first, last,
                                      nmodes, tables, scal, cand, cand_upper, front));
+            if (timed) {
+                PSA_HIP(hipEventRecord(c->ev[3], front));
+                c->last_kernel = "psa_count_duo_kernel";
+                c->last_kernel_queries = count;
+            }
             hipEvent_t done = c->pool_events[q0];
             PSA_HIP(hipEventRecord(done, front));
             PSA_HIP(hipStreamWaitEvent(c->aux, done, 0));
@@ -1417,7 +1428,9 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
             SearchSlot s0 = pool_view(0, q);
             SearchSlot s1 = pool_view(nmodes - 1, q);
             c->seq = seq0 + q;
-            PSA_TRY(launch_filter_front(c, s0, plan, first, last, front, false, tables[0], nmodes == 2 ? &s1 : nullptr, &tables[1]));
+            PSA_TRY(launch_filter_front(c, s0, plan, first, last, front, c->profiling && q == 0, tables[0],
+                                        nmodes == 2 ? &s1 : nullptr, &tables[1]));
+            if (q == 0) c->last_kernel_queries = 1;
             PSA_HIP(hipEventRecord(s0.front_done, front));
             PSA_HIP(hipStreamWaitEvent(c->aux, s0.front_done, 0));
             PSA_TRY(launch_filter_back(c, s0, pairs, c->aux, tables[0], c->batch_rescore_grid));
@@ -1453,6 +1466,10 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
     }
     PSA_HIP(hipStreamSynchronize(c->aux));
     if (twin) PSA_HIP(hipStreamSynchronize(c->twin));
+    if (c->profiling && pooled) {
+        PSA_HIP(hipEventRecord(c->ev[1], c->stream));      // whole batch; ev[2..3]: its first count launch
+        c->timing_valid = true;
+    }
     PSA_HIP(hipStreamSynchronize(c->stream));
     int bad = 0;
     for (int k = 0; k < nq * nmodes; ++k) bad |= c->h_tails[k].bad;
@@ -1659,6 +1676,10 @@ psa_status psa_last_timing(psa_context* c, int which, float* ms, const char** ke
     if (kernel_name) *kernel_name = c->last_kernel;
     return PSA_OK;
 }
+
+// Queries covered by the kernel launch psa_last_timing(which = 1) timed: 1 for a single search, the
+// queries of the first count launch for a profiled batch.
+int psa_last_kernel_queries(psa_context* c) { return c ? c->last_kernel_queries : 0; }
 
 // How many filter searches of this context overflowed the candidate list and
 // were redone by the sequential engine (tests; adversarial inputs only).

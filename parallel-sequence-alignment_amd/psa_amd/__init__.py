@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "psa_search_batch_minmax", "psa_search_batch_minmax_device",
     "psa_debug_counts", "psa_fallback_count", "psa_debug_rescore",
     "psa_fold", "psa_shard_range", "psa_build_tables",
-    "psa_set_profiling", "psa_last_timing", "psa_profile_totals",
+    "psa_set_profiling", "psa_last_timing", "psa_profile_totals", "psa_last_kernel_queries",
     "psa_generate_sequence", "psa_last_error", "psa_version",
 )
 
@@ -96,6 +96,7 @@ def _load() -> C.CDLL:
     lib.psa_set_profiling.argtypes = [vp, i]
     lib.psa_last_timing.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_char_p)]
     lib.psa_profile_totals.argtypes = [vp, dp, dp, C.POINTER(i)]
+    lib.psa_last_kernel_queries.argtypes = [vp]
     lib.psa_generate_sequence.argtypes = [C.c_uint64, i, C.c_char_p]
     lib.psa_generate_sequence.restype = None
     lib.gpu_run_program.argtypes = [vp, C.POINTER(Mutant), i, i]
@@ -315,6 +316,10 @@ class Context:
         name = C.c_char_p()
         _check(lib.psa_last_timing(self._h, which, C.byref(ms), C.byref(name)))
         return ms.value, (name.value or b"").decode()
+
+    def last_kernel_queries(self) -> int:
+        """Queries covered by the kernel launch last_timing(1) timed (1 for a single search)."""
+        return lib.psa_last_kernel_queries(self._h)
 
     def profile_totals(self):
         """(sum of search ms, sum of dominant-kernel ms, searches) since set_profiling(True)."""
