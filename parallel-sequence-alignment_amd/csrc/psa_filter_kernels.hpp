@@ -710,7 +710,17 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
 #endif
     for (int q = group; q < a.nq; q += 2) {
         PSA_DPHASE(0);
-        __builtin_amdgcn_s_setprio(0);
+        // younger waves of the group first: the hardware favours the oldest wave, which would finish its share
+        // long before the others and wait for them at the first epilogue barrier
+        {
+            int prio = (gw >> 1) + group;          // and the younger group a notch above the older one
+            switch (prio) {
+            case 0: __builtin_amdgcn_s_setprio(0); break;
+            case 1: __builtin_amdgcn_s_setprio(1); break;
+            case 2: __builtin_amdgcn_s_setprio(2); break;
+            default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        }
         // ---- main loop: this wave's chars of query q against the whole tile
         SlicedCounterT<kDuoPlanes> cnt[2][kCounters];
 #pragma unroll
