@@ -71,12 +71,14 @@ def query_block(nq, world, rank):
     return lo, hi
 
 
-def cpu_baseline(s1, s2, total, m, budget_s=12.0):
+def cpu_baseline(s1, s2, total, m, budget_s=9.0, threads=None):
     """The oracle (reference-faithful per-pair work, OpenMP static split like
     cpu_funcs.c:174-199) timed on this host's cores over a contiguous slice of
     query 0's offsets sized for ~budget_s of CPU time."""
     from oracle import oracle
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if threads:
+        cores = min(cores, threads)
     probe = min(total, 64 * cores)
     t0 = time.perf_counter()
     oracle.search(s1, s2, WEIGHTS, True, 0, probe, threads=cores)
@@ -325,6 +327,8 @@ def main():
         line["config"]["emulated_world"] = args.emulate_world
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(s1.tobytes(), queries[0].tobytes(), total, m)
+        # the reference's own thread count (THREADS_COUNT, def.h:18)
+        line["cpu_baseline_4_threads"] = cpu_baseline(s1.tobytes(), queries[0].tobytes(), total, m, budget_s=4.0, threads=4)
     if rank == 0:
         print(json.dumps(line), flush=True)
     ctx.close()
