@@ -556,6 +556,42 @@ def test_batch_minmax_full_size(psa):
             assert (res.offset, res.char_offset, chr(res.ch), "%.17g" % res.score) == (g["offset"], g["char_offset"], g["ch"], g["score"])
 
 
+def test_batch_shapes_against_sequential_engine(psa):
+    """Batch kernels over many shapes (|Seq2| around the wave / round / plan boundaries, ragged ranges, odd query
+    counts, MIN+MAX): every result equals the sequential engine's answer for that query (an independent kernel
+    whose per-offset sums are the reference's own additions)."""
+    rng = np.random.default_rng(77)
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    shapes = [(70_000, 31, 3), (70_000, 256, 2), (70_000, 257, 5), (120_000, 1023, 4), (120_000, 1024, 3),
+              (200_000, 5000, 7), (300_000, 12_256, 3), (300_000, 12_257, 2), (300_000, 16_128, 2),
+              (90_000, 40_000, 2), (1_000_000, 700, 33), (50_000, 8, 9)]
+    with psa.Context(0) as cf, psa.Context(0) as cs:
+        cf.set_engine(psa.ENGINE_FILTER)
+        cs.set_engine(psa.ENGINE_SEQUENTIAL)
+        for n, m, nq in shapes:
+            s1 = psa.generate_sequence_np(int(rng.integers(1, 1 << 30)), n).tobytes()
+            qs = [psa.generate_sequence_np(int(rng.integers(1, 1 << 30)), m).tobytes() for _ in range(nq)]
+            if m <= 5000:
+                o = int(rng.integers(0, n - m))
+                qs[-1] = s1[o:o + m]                               # an exact copy somewhere
+            total = n - m + 1
+            first = int(rng.integers(0, max(1, total // 3)))
+            last = int(rng.integers(max(first + 1, 2 * total // 3), total + 1))
+            w = [float(x) for x in rng.choice([0.25, 0.5, 1.0, 1.5, 2.6, 0.3, 0.2, 7.0], 4)]
+            for c in (cf, cs):
+                c.set_weights(w, True)
+                c.set_seq1(s1)
+            hi, lo = cf.search_batch_minmax(qs, first, last)
+            one = cf.search_batch(qs, first, last)
+            for mode, got in ((True, hi), (False, lo)):
+                cs.set_weights(w, mode)
+                for q, r in zip(qs, got):
+                    cs.set_seq2(q)
+                    assert key(r) == key(cs.search(first, last)), (n, m, nq, mode)
+            assert [key(r) for r in one] == [key(r) for r in hi]
+        assert cf.fallback_count() == 0
+
+
 def test_drop_in_program(psa, tmp_path):
     """host/psa_main: ./input.txt -> ./output.txt byte-for-byte, the reference's stdout lines and exit codes
     (main.c:13-56, cpu_funcs.c:25-121)."""
