@@ -21,9 +21,11 @@ with psa.Context(0) as cf, psa.Context(0) as cs:
     cf.set_engine(psa.ENGINE_FILTER)
     cs.set_engine(psa.ENGINE_SEQUENTIAL)
     while time.time() < t_end:
-        n = int(rng.choice([3000, 40_000, 250_000, 1_000_000, 2_500_000]))
-        m = int(min(n - 1, rng.choice([1, 7, 33, 100, 640, 1025, 2500, 9999, 12_256, 13_000, 20_000])))
-        nq = int(rng.integers(1, 6))
+        big = os.environ.get("SOAK_BIG") == "1"            # only shapes that keep the GPU busy
+        n = int(rng.choice([250_000, 1_000_000, 2_500_000] if big else [3000, 40_000, 250_000, 1_000_000, 2_500_000]))
+        m = int(min(n - 1, rng.choice([640, 1025, 2500, 9999, 12_256, 13_000, 20_000] if big else
+                                      [1, 7, 33, 100, 640, 1025, 2500, 9999, 12_256, 13_000, 20_000])))
+        nq = int(rng.integers(2, 40)) if big else int(rng.integers(1, 6))
         ab = np.frombuffer(alphabets[int(rng.integers(len(alphabets)))], np.uint8)
         s1 = rng.choice(ab, n).astype(np.uint8).tobytes()
         qs = [rng.choice(ab, m).astype(np.uint8).tobytes() for _ in range(nq)]
