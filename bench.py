@@ -270,6 +270,25 @@ def main():
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(kernel_name)
 
+    # The physical bound of the count kernels is VALU issue: wave-instructions per launch from the committed PMC
+    # profile (SQ_INSTS_VALU) over the live kernel time, against 1024 SIMDs x 1 wave64 instruction per 2 cycles at
+    # 2.4 GHz (the full-rate ops; the loop's v_alignbit_b32 issue at half of that).
+    valu = None
+    cpath = os.path.join(ROOT, "profiles", "r01_filter_counters.csv")
+    if os.path.exists(cpath):
+        import csv
+        for row in csv.DictReader(open(cpath)):
+            if row["counter"] == "SQ_INSTS_VALU" and kernel_name.split("<")[0] in row["kernel"] and \
+                    (("<" not in kernel_name) or kernel_name in row["kernel"]):
+                insts = float(row["mean_per_dispatch"])
+                if "duo" in kernel_name:
+                    insts *= kernel_queries / 32.0          # the profile's launches served 32 queries each
+                peak = 1024 * 2.4e9 / 2
+                valu = {"wave_instructions_per_launch": insts, "achieved_per_s": insts / kernel_s, "peak_per_s": peak,
+                        "frac": insts / kernel_s / peak,
+                        "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per full-rate wave64 instruction"}
+                break
+
     # Calibration of the achievable HBM bandwidth on this GPU: device-to-device copy of 1 GiB,
     # read + write counted.  Beside it, the kernel's MEASURED HBM rate = PMC traffic per launch / duration.
     copy_gbs = None
@@ -316,6 +335,7 @@ def main():
                                               "achieved": BYTES_PER_PAIR * (hi1 - lo1) * m / single_kernel_s / 1e9},
                      "measured_hbm_GBps": (traffic / kernel_s / 1e9) if traffic else None,
                      "hbm_copy_calibration_GBps": copy_gbs,
+                     "valu": valu,
                      "algorithmic_bytes_per_launch": BYTES_PER_PAIR * pairs_launch,
                      "note": "algorithmic bytes = 2 B per char pair (SURVEY.md 8d); tiles are reused from "
                              "LDS/L2 so physical HBM traffic is a few MB per search (frac > 1 is expected: "
