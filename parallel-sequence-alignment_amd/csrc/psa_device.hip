@@ -987,8 +987,13 @@ bool use_filter(const psa_context* c, int first, int last, int m)
 {
     if (c->engine == PSA_ENGINE_SEQUENTIAL) return false;
     if (c->engine == PSA_ENGINE_FILTER) return true;
-    // the filter's fixed cost (several small launches) only pays off on big searches
-    return (long long)(last - first) * m >= 20000000ll;
+    // Measured on MI355X (tools/engine_threshold.py), microseconds per blocking search: the sequential engine
+    // is a serial chain of m additions per lane, the filter engine has the larger fixed cost (two kernels,
+    // plane build, epilogue) and 15x the throughput.
+    const double pairs = (double)(last - first) * m;
+    const double t_sequential = 25.0 + 0.034 * m + pairs / 5.9e6;
+    const double t_filter = 45.0 + 0.0125 * m + pairs / 6.0e7;
+    return t_filter < t_sequential;
 }
 
 psa_status check_ready(psa_context* c, int m, int first, int last)
