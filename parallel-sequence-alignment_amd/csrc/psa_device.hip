@@ -1730,8 +1730,12 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
     }
     psa_context* c = g_legacy_ctx;
     if (psa_set_weights(c, weights, is_max) != PSA_OK) legacy_die("Failed to build the score tables");
-    if (psa_set_seq1(c, seq1, n) != PSA_OK) legacy_die("Failed to copy data from host to device (seq1)");
-    if (psa_set_seq2(c, seq2, m) != PSA_OK) legacy_die("Failed to copy data from host to device (seq2)");
+    // Both sequences go through the one staging buffer in stream order (copy, encode, copy, encode) and the
+    // call synchronises once, at the end of the search: the alphabet flag comes back with the result tail.
+    if (n < 1 || ensure_device(c) != PSA_OK || stage_host(c, seq1, (size_t)n) != PSA_OK || encode_seq1(c, c->d_raw, n) != PSA_OK)
+        legacy_die("Failed to copy data from host to device (seq1)");
+    if (stage_host(c, seq2, (size_t)m) != PSA_OK || encode_seq2(c, c->slot[0], c->d_raw, m, c->stream) != PSA_OK)
+        legacy_die("Failed to copy data from host to device (seq2)");
     psa_result r;
     if (psa_search(c, first_offset, last_offset, &r) != PSA_OK) legacy_die("Failed to run the search");
     if (r.offset < 0 || r.ch == 0) return none;   // cuda_funcs.cu:143-144
