@@ -71,12 +71,31 @@ def query_block(nq, world, rank):
     return lo, hi
 
 
+def host_cores():
+    """CPUs this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes expose
+    all 256 hardware threads in the mask but grant a share of them)."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = min(cores, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                cores = min(cores, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
 def cpu_baseline(s1, s2, total, m, budget_s=9.0, threads=None):
     """The oracle (reference-faithful per-pair work, OpenMP static split like
     cpu_funcs.c:174-199) timed on this host's cores over a contiguous slice of
     query 0's offsets sized for ~budget_s of CPU time."""
     from oracle import oracle
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     if threads:
         cores = min(cores, threads)
     probe = min(total, 64 * cores)
