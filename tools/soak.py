@@ -17,7 +17,7 @@ key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
 alphabets = [b"ABCDEFGHIJKLMNOPQRSTUVWXYZ", b"ACDEFGHIKLMNPQRSTVWY", b"ACGT", b"AL-", b"NDEQKSTA-MILV", b"AB"]
 t_end = time.time() + budget
 cases = 0
-with psa.Context(0) as cf, psa.Context(0) as cs:
+with psa.Context(0) as cf, psa.Context(0) as cs, psa.Context(0) as ca:      # ca: PSA_ENGINE_AUTO
     cf.set_engine(psa.ENGINE_FILTER)
     cs.set_engine(psa.ENGINE_SEQUENTIAL)
     while time.time() < t_end:
@@ -36,7 +36,7 @@ with psa.Context(0) as cf, psa.Context(0) as cs:
         total = n - m + 1
         first = int(rng.integers(0, max(1, total // 2)))
         last = int(rng.integers(first + 1, total + 1))
-        for c in (cf, cs):
+        for c in (cf, cs, ca):
             c.set_weights(w, True)
             c.set_seq1(s1)
         hi, lo = cf.search_batch_minmax(qs, first, last)
@@ -44,6 +44,8 @@ with psa.Context(0) as cf, psa.Context(0) as cs:
         cf.set_seq2(qs[-1])
         single = cf.search(first, last)
         assert key(single) == key(one[-1]), ("single vs batch", n, m, nq, w, first, last)
+        ca.set_seq2(qs[-1])
+        assert key(ca.search(first, last)) == key(single), ("auto engine", n, m, nq, w, first, last)
         assert [key(r) for r in one] == [key(r) for r in hi], ("batch vs minmax", n, m, nq, w, first, last)
         for mode, got in ((True, hi), (False, lo)):
             cs.set_weights(w, mode)
