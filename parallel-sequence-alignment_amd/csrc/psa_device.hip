@@ -86,7 +86,8 @@ namespace psa {
 // encode kernels: ASCII -> codes (psa_internal.hpp), flag anything else
 // ---------------------------------------------------------------------------
 __global__ void psa_encode_seq2(const unsigned char* __restrict__ raw, int m, unsigned int* __restrict__ rows,
-                                unsigned char* __restrict__ bytes, int capacity, int* __restrict__ bad)
+                                unsigned char* __restrict__ bytes, unsigned int* __restrict__ classes, int capacity,
+                                int class_chars, int class_total, int* __restrict__ bad)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= capacity) return;
@@ -96,8 +97,11 @@ __global__ void psa_encode_seq2(const unsigned char* __restrict__ raw, int m, un
         code = (c >= 'A' && c <= 'Z') ? c - 'A' : (c == '-' ? kCodeHyphen : kCodeBad);
         if (code == kCodeBad) { atomicOr(bad, 2); code = kCodePad; }
     }
-    rows[i] = (unsigned int)code << kRowShift;    // symbol as a 4 KiB row offset (count kernel); the
-    bytes[i] = (unsigned char)code;               // sequential engine shifts it back to a table row
+    rows[i] = (unsigned int)code << kRowShift;    // symbol as a 4 KiB row offset; the sequential engine
+    bytes[i] = (unsigned char)code;               // shifts it back to a table row
+    // the same symbols in the count kernels' class order (psa_filter_kernels.hpp: class_index)
+    if (i < class_total) classes[class_index(i, class_chars)] = (unsigned int)code << kRowShift;
+    else if (i < class_total + kUnroll) classes[i] = (unsigned int)kCodePad << kRowShift;
 }
 
 // ---------------------------------------------------------------------------
@@ -324,8 +328,7 @@ struct Scalars {                      // small device-side state of one filter s
 struct FilterPlan {
     int waves = 0;        // 8 or 16 waves per workgroup
     int nchunks = 0;      // char chunks (grid.y)
-    int chunk_chars = 0;
-    int wave_chars = 0;
+    int class_chars = 0;  // chars of every shift class per chunk (a chunk covers 32 x class_chars chars)
     int lds_slots = 0;
     int row_slots = 0;    // distance of two plane rows in LDS (kRowSlots for 16 waves, packed for 8)
     int lds_bytes = 0;
@@ -348,8 +351,11 @@ struct SearchSlot {
     int m = -1, m_cap = 0;
     unsigned int*       d_s2rows = nullptr;    // owned: Seq2 codes as u32 (sequential engine: scalar loads)
     unsigned char*      d_s2bytes = nullptr;   // owned: Seq2 codes as bytes (filter engine)
+    unsigned int*       d_s2cls = nullptr;     // owned: Seq2 codes as u32 in the count kernels' class order
+    int                 cls_chars = 0, cls_chunks = 0;   // the chunking d_s2cls is laid out for
     const unsigned int*  s2rows = nullptr;     // the codes this slot searches: its own buffers, or one
     const unsigned char* s2bytes = nullptr;    // query of the batch buffer
+    const unsigned int*  s2cls = nullptr;
     bool                inline_select = false; // the count kernel picked the candidates itself
     bool                scal_dirty = false;    // a filter search was enqueued and its self-reset not confirmed yet
     psa::BlockRec*      d_blocks = nullptr;    int blocks_cap = 0;      // sequential engine
@@ -410,6 +416,7 @@ struct psa_context {
     psa::SearchTail* h_tails = nullptr;   int tails_cap = 0;
     psa::SearchTail* hd_tails = nullptr;
     unsigned int*  d_batch_rows = nullptr;   // codes of all queries of a batch
+    unsigned int*  d_batch_cls = nullptr;    // the same in the count kernels' class order
     unsigned char* d_batch_bytes = nullptr;  size_t batch_cap = 0;
     // per-query search state of a batch (no buffer is reused inside a batch, so the main
     // stream never has to wait for the re-score stream)
@@ -557,21 +564,46 @@ psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
     return PSA_OK;
 }
 
+bool plan_filter(int first, int last, int m, FilterPlan* best);
+
 psa_status encode_seq2(psa_context* c, SearchSlot& s, const void* d_raw, int m, hipStream_t stream)
 {
     const int need = (m + kSeq2Slack + 63) & ~63;
     if (need > s.m_cap) {
         PSA_TRY(dev_alloc(&s.d_s2rows, (size_t)need));
         PSA_TRY(dev_alloc(&s.d_s2bytes, (size_t)need));
+        PSA_TRY(dev_alloc(&s.d_s2cls, (size_t)need));
         s.m_cap = need;
     }
     s.m = -1;
+    // class order for the chunking a search over every offset will use (a search of another range
+    // that plans differently re-orders them: ensure_class_order)
+    FilterPlan p;
+    const int total = c->n >= m ? c->n - m + 1 : psa::kTileStride * 256;
+    if (!plan_filter(0, total, m, &p)) { p.class_chars = 0; p.nchunks = 0; }
     hipLaunchKernelGGL(psa::psa_encode_seq2, dim3((s.m_cap + 255) / 256), dim3(256), 0, stream,
-                       static_cast<const unsigned char*>(d_raw), m, s.d_s2rows, s.d_s2bytes, s.m_cap, c->d_bad);
+                       static_cast<const unsigned char*>(d_raw), m, s.d_s2rows, s.d_s2bytes, s.d_s2cls, s.m_cap,
+                       p.class_chars, p.nchunks * psa::kClasses * p.class_chars, c->d_bad);
     PSA_HIP(hipGetLastError());
     s.m = m;
+    s.cls_chars = p.class_chars;
+    s.cls_chunks = p.nchunks;
     s.s2rows = s.d_s2rows;
     s.s2bytes = s.d_s2bytes;
+    s.s2cls = s.d_s2cls;
+    return PSA_OK;
+}
+
+// the slot's own Seq2 in the class order of plan `p`
+psa_status ensure_class_order(SearchSlot& s, const FilterPlan& p, hipStream_t stream)
+{
+    if (s.s2cls != s.d_s2cls || (s.cls_chars == p.class_chars && s.cls_chunks == p.nchunks)) return PSA_OK;
+    const int class_total = p.nchunks * psa::kClasses * p.class_chars;
+    hipLaunchKernelGGL(psa::psa_class_order_kernel, dim3((class_total + psa::kUnroll + 255) / 256), dim3(256), 0, stream,
+                       s.d_s2bytes, s.m, s.d_s2cls, p.class_chars, class_total);
+    PSA_HIP(hipGetLastError());
+    s.cls_chars = p.class_chars;
+    s.cls_chunks = p.nchunks;
     return PSA_OK;
 }
 
@@ -682,26 +714,34 @@ int exchange_bytes(int waves)
     return (waves / 2) * (2 * psa::kCounters * psa::kPlanes) * 64 * 4;
 }
 
+// Largest chunk count a Seq2 class buffer is sized for (every chunk rounds its classes up to whole rounds)
+constexpr int kMaxChunks = 24;
+static_assert((kMaxChunks + 1) * psa::kClasses * psa::kUnroll + psa::kUnroll <= kSeq2Slack, "class-order buffer");
+
 bool plan_filter(int first, int last, int m, FilterPlan* best)
 {
-    const int ntiles = (last - (first & ~31) + psa::kTile - 1) / psa::kTile;
+    const int ntiles = (last - (first & ~31) + psa::kTileStride - 1) / psa::kTileStride;
     const int publish = psa::kCounters * psa::kMergedPlanes * 128 * 4;
+    const int rounds_total = ((m + psa::kClasses - 1) / psa::kClasses + psa::kUnroll - 1) / psa::kUnroll;   // per class
     double best_cost = 0.0;
     bool found = false;
-    // experiment knobs (not part of the API): force the workgroup shape / chunk count
+#ifdef PSA_EXPERIMENT
+    // experiment knobs (not part of the API, compiled out of the product build): force the workgroup shape / chunk count
     static const int force_waves = std::getenv("PSA_FILTER_WAVES") ? std::atoi(std::getenv("PSA_FILTER_WAVES")) : 0;
     static const int force_chunks = std::getenv("PSA_FILTER_CHUNKS") ? std::atoi(std::getenv("PSA_FILTER_CHUNKS")) : 0;
+#else
+    constexpr int force_waves = 0, force_chunks = 0;
+#endif
     for (int waves : {16, 8}) {
         if (force_waves && waves != force_waves) continue;
-        const int gran = waves * psa::kUnroll;
-        for (int nchunks = 1; nchunks <= 64; ++nchunks) {
+        const int wave_classes = psa::kClasses / waves;
+        for (int nchunks = 1; nchunks <= kMaxChunks && nchunks <= rounds_total; ++nchunks) {
             if (force_chunks && nchunks != force_chunks) continue;
-            int chunk = (m + nchunks - 1) / nchunks;
-            chunk = (chunk + gran - 1) / gran * gran;
-            if ((long long)chunk * (nchunks - 1) >= m && nchunks > 1) continue;   // last chunk would be empty
-            const int wave_chars = chunk / waves;
-            if (wave_chars > psa::kMaxWaveChars) continue;
-            const int slots = chunk / 32 + 129;
+            const int rounds = (rounds_total + nchunks - 1) / nchunks;
+            if (nchunks > 1 && rounds * (nchunks - 1) >= rounds_total) continue;   // last chunk would be empty
+            const int class_chars = rounds * psa::kUnroll;
+            if (wave_classes * class_chars > psa::kMaxWaveChars) continue;
+            const int slots = psa::kTile / 32 + class_chars + 1;
             if (slots > psa::kRowSlots) continue;             // rows are at most kRowSlots slots apart in LDS
             // 16 waves: rows 4 KiB apart (a symbol is its row offset); 8 waves: rows packed, two workgroups per CU
             const int row_slots = waves == 16 ? psa::kRowSlots : slots;
@@ -713,19 +753,19 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
             int per_cu = kLdsLimit / lds;
             if (per_cu > 16 / waves) per_cu = 16 / waves;
             const long long blocks = (long long)ntiles * nchunks;
-            const long long rounds = (blocks + 256 * per_cu - 1) / (256 * per_cu);   // waves of co-resident workgroups
-            // VALU-bound: ~12.3 CU-cycles per char of a workgroup alone on its CU, plus staging and the epilogue; the
-            // chunk workgroups of a tile meet through memory (stores, L2 write-back, arrival, read-back: ~10 us)
-            const double block_cost = 12.3 * chunk * per_cu + 0.5 * psa::kMaskRows * slots + 4000.0 +
+            const long long rounds_cu = (blocks + 256 * per_cu - 1) / (256 * per_cu);   // waves of co-resident workgroups
+            // VALU-bound: ~8 CU-cycles per char of a workgroup alone on its CU, plus staging, the class shifts and
+            // the epilogue; the chunk workgroups of a tile meet through memory (stores, L2 write-back, arrival,
+            // read-back: ~10 us)
+            const double block_cost = 8.0 * psa::kClasses * class_chars * per_cu + 0.5 * psa::kMaskRows * slots + 5000.0 +
                                       (nchunks > 1 ? 20000.0 : 0.0);
-            const double cost = (double)rounds * block_cost;     // co-resident workgroups share the CU's VALU
+            const double cost = (double)rounds_cu * block_cost;     // co-resident workgroups share the CU's VALU
             if (!found || cost < best_cost) {
                 found = true;
                 best_cost = cost;
                 best->waves = waves;
                 best->nchunks = nchunks;
-                best->chunk_chars = chunk;
-                best->wave_chars = wave_chars;
+                best->class_chars = class_chars;
                 best->lds_slots = slots;
                 best->row_slots = row_slots;
                 best->lds_bytes = lds;
@@ -774,12 +814,11 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     psa::CountArgs a;
     a.s1 = c->d_s1;
     a.symbol_planes = c->d_symbol_planes;
-    a.s2off = s.s2rows;
+    a.classes = s.s2cls;
     a.partial = s.d_partial;
     a.base = base;
     a.span_pad = span_pad;
-    a.chunk_chars = p.chunk_chars;
-    a.wave_chars = p.wave_chars;
+    a.class_chars = p.class_chars;
     a.lds_slots = p.lds_slots;
     a.row_slots = p.row_slots;
     a.row_mul = (unsigned)(8 * p.row_slots) << 20;
@@ -828,29 +867,31 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
 
 // Batches: queries [q, q+count) of a pooled batch through psa_count_duo_kernel.  `scal`, `cand`, `cand_upper`
 // are the pool entries of query q in each mode.
-bool duo_fits(int m, int* wave_chars, int* lds_slots)
+bool duo_fits(int m, int* class_chars, int* lds_slots)
 {
-    int wc = (m + psa::kDuoGroupWaves - 1) / psa::kDuoGroupWaves;
-    wc = (wc + psa::kUnroll - 1) / psa::kUnroll * psa::kUnroll;
-    const int slots = psa::kDuoGroupWaves * wc / 32 + 129;
-    if (wc > psa::kDuoMaxWaveChars || slots > psa::kRowSlots || psa::kDuoLdsBytes > kLdsLimit) return false;
-    *wave_chars = wc;
+    const int rounds = ((m + psa::kClasses - 1) / psa::kClasses + psa::kUnroll - 1) / psa::kUnroll;
+    const int cc = rounds * psa::kUnroll;
+    const int slots = psa::kTile / 32 + cc + 1;
+    if ((psa::kClasses / psa::kDuoGroupWaves) * cc > psa::kDuoMaxWaveChars || slots > psa::kRowSlots ||
+        psa::kDuoLdsBytes > kLdsLimit)
+        return false;
+    *class_chars = cc;
     *lds_slots = slots;
     return true;
 }
 
-psa_status launch_count_duo(psa_context* c, const unsigned* s2rows, size_t s2_stride, int m, int count, int first, int last,
+psa_status launch_count_duo(psa_context* c, const unsigned* s2cls, size_t s2_stride, int m, int count, int first, int last,
                             int nmodes, const TableSet* tables, Scalars* const scal[2], int* const cand[2],
                             double* const cand_upper[2], hipStream_t stream)
 {
     static_assert(sizeof(Scalars) == psa::kScalStride && offsetof(Scalars, cand_count) == psa::kScalCountOffset,
                   "psa_count_duo_kernel addresses the pool scalars by these strides");
     psa::DuoArgs a;
-    if (!duo_fits(m, &a.wave_chars, &a.lds_slots)) { set_last_error("internal: duo kernel does not fit"); return PSA_ERR_ARG; }
+    if (!duo_fits(m, &a.class_chars, &a.lds_slots)) { set_last_error("internal: duo kernel does not fit"); return PSA_ERR_ARG; }
     const int base = first & ~31;
     a.s1 = c->d_s1;
     a.symbol_planes = c->d_symbol_planes;
-    a.s2off = s2rows;
+    a.classes = s2cls;
     a.s2_stride = s2_stride;
     a.base = base;
     a.nq = count;
@@ -873,7 +914,7 @@ psa_status launch_count_duo(psa_context* c, const unsigned* s2rows, size_t s2_st
                                     hipFuncAttributeMaxDynamicSharedMemorySize, psa::kDuoLdsBytes));
         c->granted_duo = true;
     }
-    const int ntiles = (last - base + psa::kTile - 1) / psa::kTile;
+    const int ntiles = (last - base + psa::kTileStride - 1) / psa::kTileStride;
     hipLaunchKernelGGL(psa::psa_count_duo_kernel, dim3(ntiles), dim3(1024), psa::kDuoLdsBytes, stream, a);
     PSA_HIP(hipGetLastError());
     return PSA_OK;
@@ -906,7 +947,7 @@ psa_status plan_on_slot(SearchSlot& s, int first, int last, hipStream_t stream, 
         return PSA_ERR_ARG;
     }
     if (p->nchunks > 1) PSA_TRY(ensure_chunk_scratch(&s.d_partial, &s.partial_cap, &s.d_arrivals, &s.arrivals_cap, *p, stream));
-    return PSA_OK;
+    return ensure_class_order(s, *p, stream);
 }
 
 // count + bounds + candidate selection: one kernel (chunk workgroups of a tile combine in the kernel)
@@ -986,6 +1027,8 @@ psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hi
 bool use_filter(const psa_context* c, int first, int last, int m)
 {
     if (c->engine == PSA_ENGINE_SEQUENTIAL) return false;
+    FilterPlan p;
+    if (!plan_filter(first, last, m, &p)) return false;      // Seq2 beyond what the count kernels chunk
     if (c->engine == PSA_ENGINE_FILTER) return true;
     // Measured on MI355X (tools/engine_threshold.py), microseconds per blocking search: the sequential engine
     // is a serial chain of m additions per lane, the filter engine has the larger fixed cost (two kernels,
@@ -1049,6 +1092,7 @@ void free_slot(SearchSlot& s)
 {
     (void)hipFree(s.d_s2rows);
     (void)hipFree(s.d_s2bytes);
+    (void)hipFree(s.d_s2cls);
     (void)hipFree(s.d_blocks);
     (void)hipFree(s.d_partial);
     (void)hipFree(s.d_arrivals);
@@ -1150,6 +1194,7 @@ void psa_destroy(psa_context* c)
     (void)hipFree(c->d_bad);
     for (auto& s : c->slot) free_slot(s);
     (void)hipFree(c->d_batch_rows);
+    (void)hipFree(c->d_batch_cls);
     (void)hipFree(c->d_batch_bytes);
     (void)hipFree(c->d_pool_scal);
     (void)hipFree(c->d_pool_cand);
@@ -1336,13 +1381,14 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
     if ((size_t)nq * ostride > c->batch_cap) {
         c->batch_cap = 0;
         PSA_TRY(dev_alloc(&c->d_batch_rows, (size_t)nq * ostride));
+        PSA_TRY(dev_alloc(&c->d_batch_cls, (size_t)nq * ostride));
         PSA_TRY(dev_alloc(&c->d_batch_bytes, (size_t)nq * ostride));
         c->batch_cap = (size_t)nq * ostride;
     }
-    // single-chunk filter plans keep all per-query state in pools (entry mode*nq + q): nothing is
+    // filter searches keep all per-query state in pools (entry mode*nq + q): nothing is
     // reused inside the batch and the count kernels never wait for the re-score stream
     FilterPlan plan;
-    const bool pooled = filter && plan_filter(first, last, m, &plan);
+    const bool pooled = filter && plan_filter(first, last, m, &plan);      // filter => a plan exists (use_filter)
     static_assert(sizeof(Scalars) % sizeof(unsigned long long) == 0, "the encode kernel zeroes the pool in 8-byte words");
     int zero_words = 0;
     if (pooled) {
@@ -1359,7 +1405,8 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
         for (auto& s : c->slot) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
     }
     hipLaunchKernelGGL(psa::psa_encode_batch_kernel, dim3((ostride + 255) / 256, nq), dim3(256), 0, c->stream,
-                       base, nq, m, stride, c->d_batch_rows, c->d_batch_bytes, ostride, c->d_bad,
+                       base, nq, m, stride, c->d_batch_rows, c->d_batch_bytes, c->d_batch_cls, ostride,
+                       pooled ? plan.class_chars : 0, pooled ? plan.nchunks * psa::kClasses * plan.class_chars : 0, c->d_bad,
                        reinterpret_cast<unsigned long long*>(c->d_pool_scal), zero_words);
     PSA_HIP(hipGetLastError());
     // the other streams must see everything already enqueued on the main stream (Seq1 codes, tables, query codes)
@@ -1384,6 +1431,7 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
         v.m = m;
         v.s2rows = c->d_batch_rows + (size_t)q * ostride;
         v.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
+        v.s2cls = c->d_batch_cls + (size_t)q * ostride;
         v.d_partial = c->d_ring_partial[q & 1];          // queries q and q+2 run on the same stream
         v.d_arrivals = c->d_ring_arrivals[q & 1];
         return v;
@@ -1408,7 +1456,7 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
             }
             const bool timed = c->profiling && launch == 0;          // launch 0 runs on the main stream
             if (timed) PSA_HIP(hipEventRecord(c->ev[2], front));
-            PSA_TRY(launch_count_duo(c, c->d_batch_rows + (size_t)q0 * ostride, (size_t)ostride, m, count, first, last,
+            PSA_TRY(launch_count_duo(c, c->d_batch_cls + (size_t)q0 * ostride, (size_t)ostride, m, count, first, last,
                                      nmodes, tables, scal, cand, cand_upper, front));
             if (timed) {
                 PSA_HIP(hipEventRecord(c->ev[3], front));
@@ -1454,18 +1502,9 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
                 s.s2rows = c->d_batch_rows + (size_t)q * ostride;
                 s.s2bytes = c->d_batch_bytes + (size_t)q * ostride;
                 c->seq = seq_of(mode, q);
-                if (filter) {
-                    FilterPlan sp;
-                    PSA_TRY(plan_on_slot(s, first, last, c->stream, &sp));
-                    PSA_TRY(launch_filter_front(c, s, sp, first, last, c->stream, false, tables[mode]));
-                    PSA_HIP(hipEventRecord(s.front_done, c->stream));
-                    PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
-                    PSA_TRY(launch_filter_back(c, s, pairs, c->aux, tables[mode]));
-                } else {
-                    PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream, tables[mode]));
-                    PSA_HIP(hipEventRecord(s.front_done, c->stream));
-                    PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
-                }
+                PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream, tables[mode]));
+                PSA_HIP(hipEventRecord(s.front_done, c->stream));
+                PSA_HIP(hipStreamWaitEvent(c->aux, s.front_done, 0));
                 PSA_HIP(hipEventRecord(s.back_done, c->aux));
             }
     }
@@ -1595,6 +1634,7 @@ psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_sta
         PSA_TRY(dev_alloc(&s.d_partial, need));
         s.partial_cap = need;
     }
+    PSA_TRY(ensure_class_order(s, p, c->stream));
     PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, false, c->stream, primary_tables(c)));
     std::vector<unsigned long long> host(need);
     PSA_HIP(hipMemcpyAsync(host.data(), s.d_partial, need * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1603,7 +1643,9 @@ psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_sta
     PSA_TRY(report_bad(c));
     for (int o = 0; o < span; ++o) {
         unsigned long long sum = 0;
-        for (int k = 0; k < p.nchunks; ++k) sum += host[(size_t)k * span_pad + lead + o];
+        const int rel = lead + o;               // tile t answers for kTileStride offsets, stored kTile apart
+        const size_t at = (size_t)(rel / psa::kTileStride) * psa::kTile + (size_t)(rel % psa::kTileStride);
+        for (int k = 0; k < p.nchunks; ++k) sum += host[(size_t)k * span_pad + at];
         const uint32_t n_lo = (uint32_t)(sum & 0x1fffff), n_hi = (uint32_t)((sum >> 21) & 0x1fffff);
         const uint32_t n_both = (uint32_t)((sum >> 42) & 0x1fffff);
         if (n_star) n_star[o] = n_lo - n_both;

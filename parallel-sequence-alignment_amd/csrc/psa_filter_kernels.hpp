@@ -12,10 +12,21 @@
 //   n_hi(o)   = sum_i hi[Seq2[i]][o+i]    (= n_colon + n_dot)
 //   n_both(o) = sum_i (lo & hi)[...]      (= n_dot)
 //
-// One lane owns 64 offsets (two 32-bit words); for char i the planes of
-// Seq2[i] are funnel-shifted by i and added into per-lane bit-plane counters
-// with carry-save adders built from v_bitop3_b32 (xor3 / majority: 2 full-rate
-// VALU ops per 32 pairs and counter).  From the counts, a rounding bound of
+// One lane owns 64 positions (two 32-bit words) and adds plane words into per-lane
+// bit-plane counters with carry-save adders built from v_bitop3_b32 (xor3 /
+// majority: 2 VALU ops per 32 pairs and counter).  Char i of Seq2 pairs offset o
+// with Seq1 position o+i, i.e. the planes of Seq2[i] shifted by i bits.  The chars
+// are therefore grouped into 32 SHIFT CLASSES J = i mod 32: inside a class
+// (i = 32k + J) char k reads the plane word one whole slot further on, with no
+// bit shift at all — two aligned ds_read_b64 per char and no funnel shift.  With
+//     D_J[x] = sum_k plane[Seq2[32k+J]][x + 32k]      (x = position in the tile)
+// the count of offset o is sum_J D_J[o + J].  A wave walks its classes from the
+// highest J down and shifts its COUNTER planes by one bit between two classes
+// (Horner: C_J[x] = D_J[x] + C_{J+1}[x+1]; the neighbour word comes from the next
+// lane by DPP), then by its lowest J once at the end: ~170 instructions per class
+// instead of 4 half-rate v_alignbit_b32 per char.  The bits shifted in at the top
+// of the tile's last word are not the tile's: a tile of 128 words answers for its
+// first 127 words (kTileStride offsets).  From the counts, a rounding bound of
 // the reference's sequential fp64 sum (cpu_funcs.c:278) gives a score interval
 // per offset; only offsets whose interval can reach the best one are re-scored
 // in the reference's exact order (psa_rescore_kernel).  The answer is the
@@ -27,7 +38,9 @@
 
 namespace psa {
 
-constexpr int kTile = 4096;        // offsets per workgroup: 64 lanes x 2 words x 32 bits
+constexpr int kTile = 4096;        // positions per workgroup: 64 lanes x 2 words x 32 bits
+constexpr int kTileStride = kTile - 32;   // offsets a tile answers for (its last word takes the class shifts' spill)
+constexpr int kClasses = 32;       // shift classes: chars i with the same i mod 32
 constexpr int kUnroll = 32;        // chars per carry-save round (2^kLevels)
 constexpr int kLevels = 5;
 constexpr int kPlanes = 10;        // per-wave counters hold up to 1023 chars
@@ -97,10 +110,23 @@ struct SlicedCounterT {
 };
 using SlicedCounter = SlicedCounterT<kPlanes>;
 
+// ---- Seq2 in the order the count kernels read it -------------------------------
+// Char i = 32k + J belongs to shift class J.  A char chunk holds `class_chars` chars k of
+// every class; inside a chunk the classes lie from 31 down to 0 (a wave walks its classes
+// downwards, so its symbols are one ascending run and the scalar prefetch simply runs on).
+__host__ __device__ __forceinline__ size_t class_index(int i, int class_chars)
+{
+    const int J = i & (kClasses - 1), k = i >> 5;
+    const int c = k / class_chars, kk = k - c * class_chars;
+    return ((size_t)c * kClasses + (size_t)(kClasses - 1 - J)) * (size_t)class_chars + (size_t)kk;
+}
+
 // ---- Seq2 queries of a batch: ASCII -> codes, all queries in one launch -------
 __global__ __launch_bounds__(256) void psa_encode_batch_kernel(const unsigned char* __restrict__ raw, int nq, int m,
                                                                size_t in_stride, unsigned int* __restrict__ rows,
-                                                               unsigned char* __restrict__ bytes, int out_stride,
+                                                               unsigned char* __restrict__ bytes,
+                                                               unsigned int* __restrict__ classes, int out_stride,
+                                                               int class_chars, int class_total,
                                                                int* __restrict__ bad,
                                                                unsigned long long* __restrict__ zero, int zero_words)
 {
@@ -118,6 +144,19 @@ __global__ __launch_bounds__(256) void psa_encode_batch_kernel(const unsigned ch
     }
     rows[(size_t)q * out_stride + i] = (unsigned int)code << kRowShift;   // symbol as a 4 KiB row offset
     bytes[(size_t)q * out_stride + i] = (unsigned char)code;
+    // class order (count kernels); the kUnroll entries behind it are the last prefetch's padding
+    if (i < class_total) classes[(size_t)q * out_stride + class_index(i, class_chars)] = (unsigned int)code << kRowShift;
+    else if (i < class_total + kUnroll) classes[(size_t)q * out_stride + i] = (unsigned int)kCodePad << kRowShift;
+}
+
+// The class order of one Seq2 for another chunking than the one it was encoded for
+__global__ __launch_bounds__(256) void psa_class_order_kernel(const unsigned char* __restrict__ bytes, int m,
+                                                              unsigned int* __restrict__ classes, int class_chars,
+                                                              int class_total)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < class_total) classes[class_index(i, class_chars)] = (unsigned int)(i < m ? bytes[i] : kCodePad) << kRowShift;
+    else if (i < class_total + kUnroll) classes[i] = (unsigned int)kCodePad << kRowShift;
 }
 
 // ---- Seq1: ASCII -> symbol codes (32 positions per thread), alphabet validation ----
@@ -183,68 +222,114 @@ __device__ __forceinline__ void transpose32(unsigned (&a)[32])
 }
 
 // ---- LDS reads of the count loop, issued one char ahead ------------------------
-// Four plain ds_read_b64 per char (slots l, l+1, l+64, l+65 of the symbol's row): 2 LDS cycles
-// each.  Left to the compiler they are merged into ds_read2_b64 pairs (8 cycles a pair) and
-// waited for right after issue; here they are issued for char J+1 before char J is processed
-// and retired by an explicit s_waitcnt (inline asm: hipcc does not count these loads, the wait
-// statement names every destination so no consumer can be scheduled above it).
+// Two plain ds_read_b64 per char (slots l+k and l+64+k of the symbol's row): 2 LDS cycles each,
+// consecutive lanes on consecutive 8-byte slots (conflict-free).  Left to the compiler they would
+// be merged into ds_read2_b64 (8 cycles) and waited for right after issue; here they are issued
+// for char T+1 before char T is processed and retired by an explicit s_waitcnt (inline asm: hipcc
+// does not count these loads, the wait statement names every destination so no consumer can be
+// scheduled above it).
 struct SlotRegs {
-    unsigned long long v[4];
+    unsigned long long v[2];
 };
 
+template <int IMM>
 __device__ __forceinline__ void lds_issue(SlotRegs& n, unsigned addr)
 {
-    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:8\n\t"
-                 "ds_read_b64 %2, %4 offset:512\n\tds_read_b64 %3, %4 offset:520"
-                 : "=&v"(n.v[0]), "=&v"(n.v[1]), "=&v"(n.v[2]), "=&v"(n.v[3])
-                 : "v"(addr));
+    asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4"
+                 : "=&v"(n.v[0]), "=&v"(n.v[1])
+                 : "v"(addr), "i"(IMM), "i"(IMM + 512));
 }
 
 __device__ __forceinline__ void lds_retire(SlotRegs& n)
 {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n.v[0]), "+v"(n.v[1]), "+v"(n.v[2]), "+v"(n.v[3]));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n.v[0]), "+v"(n.v[1]));
 }
 
-// One char of the count loop: J is its index inside the round.  Tiles start on
-// a 32-offset boundary and rounds on a 32-char boundary, so the funnel shift of
-// char J is the compile-time constant J and all chars of a round read the same
-// slot column.  Lane l owns words l and l+64 of the tile: consecutive lanes read
-// consecutive 8-byte slots (conflict-free).  `cur` holds this char's slots; the
-// next char's are requested first (J == 31: char 0 of the next round, one column on).
-template <int J, typename Counter>
-__device__ __forceinline__ void count_step(Counter (&cnt)[2][kCounters], SlotRegs& cur,
+// One char of a shift class: T is its index inside the round.  Char k of the class reads slot
+// l + k (word l) and l + 64 + k (word l+64) of its symbol's row: the round's base address moves
+// on by kUnroll slots per round, T is an immediate offset.  `cur` holds this char's slots; the
+// next char's are requested first (T == 31: char 0 of the next round).
+template <int T, typename Counter>
+__device__ __forceinline__ void class_step(Counter (&cnt)[2][kCounters], SlotRegs& cur,
                                            const unsigned (&rowoff)[kUnroll], unsigned next_rowoff,
                                            unsigned lane_addr)
 {
     SlotRegs nxt;
     // Seq2 symbol of the next char as a wave-uniform LDS row offset (symbol << kRowShift)
-    lds_issue(nxt, J + 1 < kUnroll ? lane_addr + rowoff[(J + 1) % kUnroll] : lane_addr + 8u + next_rowoff);
-    unsigned lo0, hi0, lo1, hi1;
-    if constexpr (J == 0) {
-        lo0 = (unsigned)cur.v[0]; hi0 = (unsigned)(cur.v[0] >> 32);
-        lo1 = (unsigned)cur.v[2]; hi1 = (unsigned)(cur.v[2] >> 32);
-    } else {
-        lo0 = __builtin_amdgcn_alignbit((unsigned)cur.v[1], (unsigned)cur.v[0], J);
-        hi0 = __builtin_amdgcn_alignbit((unsigned)(cur.v[1] >> 32), (unsigned)(cur.v[0] >> 32), J);
-        lo1 = __builtin_amdgcn_alignbit((unsigned)cur.v[3], (unsigned)cur.v[2], J);
-        hi1 = __builtin_amdgcn_alignbit((unsigned)(cur.v[3] >> 32), (unsigned)(cur.v[2] >> 32), J);
-    }
-    cnt[0][0].template push<J>(lo0);
-    cnt[0][1].template push<J>(hi0);
-    cnt[0][2].template push<J>(lo0 & hi0);
-    cnt[1][0].template push<J>(lo1);
-    cnt[1][1].template push<J>(hi1);
-    cnt[1][2].template push<J>(lo1 & hi1);
+    if constexpr (T + 1 < kUnroll) lds_issue<8 * (T + 1)>(nxt, lane_addr + rowoff[(T + 1) % kUnroll]);
+    else lds_issue<8 * kUnroll>(nxt, lane_addr + next_rowoff);
+    const unsigned lo0 = (unsigned)cur.v[0], hi0 = (unsigned)(cur.v[0] >> 32);
+    const unsigned lo1 = (unsigned)cur.v[1], hi1 = (unsigned)(cur.v[1] >> 32);
+    cnt[0][0].template push<T>(lo0);
+    cnt[0][1].template push<T>(hi0);
+    cnt[0][2].template push<T>(lo0 & hi0);
+    cnt[1][0].template push<T>(lo1);
+    cnt[1][1].template push<T>(hi1);
+    cnt[1][2].template push<T>(lo1 & hi1);
     lds_retire(nxt);
     cur = nxt;
 }
 
-template <typename Counter, int... Js>
-__device__ __forceinline__ void count_round(Counter (&cnt)[2][kCounters], SlotRegs& cur,
+template <typename Counter, int... Ts>
+__device__ __forceinline__ void class_round(Counter (&cnt)[2][kCounters], SlotRegs& cur,
                                             const unsigned (&rowoff)[kUnroll], unsigned next_rowoff,
-                                            unsigned lane_addr, std::integer_sequence<int, Js...>)
+                                            unsigned lane_addr, std::integer_sequence<int, Ts...>)
 {
-    (count_step<Js>(cnt, cur, rowoff, next_rowoff, lane_addr), ...);
+    (class_step<Ts>(cnt, cur, rowoff, next_rowoff, lane_addr), ...);
+}
+
+// Counter planes moved down by `s` bit positions (C[x] <- C[x + s], 1 <= s <= 31): word w takes
+// its upper bits from word w+1, which the next lane holds (DPP wave rotate; lane 63's word 63 is
+// followed by lane 0's word 64).  Word 127 has no successor in the tile: what lane 63 receives
+// for it (lane 0's word 64) is spill — offsets of the tile's last word are not used (kTileStride).
+template <typename Counter>
+__device__ __forceinline__ void shift_planes(Counter (&cnt)[2][kCounters], unsigned s, int lane)
+{
+    const bool last_lane = lane == 63;
+#pragma unroll
+    for (int k = 0; k < kCounters; ++k)
+#pragma unroll
+        for (int p = 0; p < (int)(sizeof(cnt[0][k].plane) / sizeof(unsigned)); ++p) {
+            const unsigned a = cnt[0][k].plane[p], b = cnt[1][k].plane[p];
+            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x134, 0xf, 0xf, false);   // wave_rol:1:
+            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x134, 0xf, 0xf, false);   // lane l <- lane l+1
+            cnt[0][k].plane[p] = __builtin_amdgcn_alignbit(last_lane ? rb : ra, a, s);
+            cnt[1][k].plane[p] = __builtin_amdgcn_alignbit(rb, b, s);
+        }
+}
+
+// The main loop of one wave: `nclasses` shift classes of `class_chars` chars each (a multiple of
+// kUnroll), highest class first.  `sym` = the wave's symbols in that order (class_index), `lane_base`
+// = LDS byte address of slot `lane` of the chunk's first column.  On return cnt holds, for the wave's
+// classes, sum_J D_J[x + J - low_class] ... shifted down by `low_class`: the wave's share of the counts.
+template <typename Counter, typename RowOf>
+__device__ __forceinline__ void count_classes(Counter (&cnt)[2][kCounters],
+                                              const __attribute__((address_space(4))) unsigned* sym,
+                                              int nclasses, int class_chars, unsigned low_class,
+                                              unsigned lane_base, int lane, RowOf row_of)
+{
+    // the row offsets of a round are fetched one round ahead, the LDS slots one char ahead;
+    // the last prefetches of a wave run past its range into valid padding and are never used
+    unsigned rowoff[kUnroll], rowoff_next[kUnroll];
+#pragma unroll
+    for (int q = 0; q < kUnroll; ++q) rowoff[q] = row_of(sym[q]);
+    for (int c = 0; c < nclasses; ++c) {
+        if (c) shift_planes(cnt, 1u, lane);              // Horner step: C[x] <- C[x+1], then add the next class
+        unsigned lane_addr = lane_base;
+        SlotRegs cur;
+        lds_issue<0>(cur, lane_addr + rowoff[0]);
+        lds_retire(cur);
+        for (int g = 0; g < class_chars; g += kUnroll) {
+            sym += kUnroll;
+#pragma unroll
+            for (int q = 0; q < kUnroll; ++q) rowoff_next[q] = row_of(sym[q]);   // wave-uniform
+            class_round(cnt, cur, rowoff, rowoff_next[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
+#pragma unroll
+            for (int q = 0; q < kUnroll; ++q) rowoff[q] = rowoff_next[q];
+            lane_addr += 8u * kUnroll;
+        }
+    }
+    if (low_class) shift_planes(cnt, low_class, lane);
 }
 
 // ---- score interval of one offset from its exact counts ------------------------
@@ -295,13 +380,12 @@ __device__ __forceinline__ void offset_bounds(const BoundParams& b, int n_lo, in
 struct CountArgs {
     const unsigned char* s1;        // Seq1 symbol codes, padded with kCodePad (32 per slot)
     const unsigned*      symbol_planes;  // [64]: class planes of every Seq1 symbol over the Seq2 symbols
-    const unsigned*      s2off;     // Seq2 symbols as LDS row offsets (code << kRowShift), padded with kCodePad
-    unsigned long long*  partial;   // [nchunks][span_pad]: n_lo | n_hi<<21 | n_both<<42
+    const unsigned*      classes;   // Seq2 symbols as LDS row offsets (code << kRowShift) in class order (class_index)
+    unsigned long long*  partial;   // [nchunks][span_pad]: n_lo | n_hi<<21 | n_both<<42; tile t at t*kTile
     int base;         // first offset of tile 0: the range's first offset rounded down to a multiple of 32
-    int span_pad;     // offsets covered = ntiles*kTile
-    int chunk_chars;  // chars per chunk (multiple of kUnroll * waves)
-    int wave_chars;   // chars per wave   (multiple of kUnroll, <= kMaxWaveChars)
-    int lds_slots;    // slots per staged row
+    int span_pad;     // ntiles*kTile
+    int class_chars;  // chars of every shift class per chunk (multiple of kUnroll); a chunk = 32 x class_chars chars
+    int lds_slots;    // slots per staged row (kTile/32 + class_chars + 1)
     int row_slots;    // distance of two rows in LDS, in slots (the 16-wave kernel uses kRowSlots)
     unsigned row_mul; // (8 * row_slots) << 20: __umulhi(code << kRowShift, row_mul) = the row's LDS byte offset
     int* tile_arrivals;   // [ntiles], zero between searches: chunk workgroups of a tile that have published their counts
@@ -339,15 +423,15 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile_o0 = a.base + blockIdx.x * kTile;           // absolute offset of word 0, bit 0 (multiple of 32)
-    const int chunk_c0 = blockIdx.y * a.chunk_chars;           // first char of this chunk (multiple of 32)
-    const int slot0 = (tile_o0 + chunk_c0) >> 5;               // first staged slot
+    const int tile_o0 = a.base + blockIdx.x * kTileStride;     // absolute offset of word 0, bit 0 (multiple of 32)
+    const int chunk_k0 = blockIdx.y * a.class_chars;           // first char k of every class in this chunk
+    const int slot0 = (tile_o0 >> 5) + chunk_k0;               // first staged slot
     // rows are 4 KiB apart in the 16-wave kernel (a Seq2 symbol, stored as code << 12, is its row's byte
     // offset); smaller workgroups pack them (two workgroups per CU) and rescale the symbol on the scalar unit
     const int row_slots = WAVES == 16 ? kRowSlots : a.row_slots;
     auto row_of = [&](unsigned sym) -> unsigned { return WAVES == 16 ? sym : __umulhi(sym, a.row_mul); };
 
-    // Build the class planes of the window [tile_o0+chunk_c0, +kTile+chunk_chars) in LDS: row b
+    // Build the class planes of the window [32*slot0, +kTile+32*class_chars) in LDS: row b
     // (Seq2 symbol), slot s holds {lo, hi}: bit t of lo = class(Seq1[32*(slot0+s)+t], b) in
     // {'*','.'}, of hi = class in {':','.'}.  A thread fetches the 32 symbol columns of its slot
     // (symbol_planes: bit b = the relation of that Seq1 symbol to b) and transposes the two 32x32
@@ -390,32 +474,18 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
 #pragma unroll
         for (int k = 0; k < kCounters; ++k) cnt[w][k].clear();
 
-    const int c_begin = chunk_c0 + wave * a.wave_chars;
+    // this wave's shift classes: low_class .. low_class + kWaveClasses - 1, walked from the top down
+    constexpr int kWaveClasses = kClasses / WAVES;
+    const int low_class = wave * kWaveClasses;
     // constant address space: keeps these wave-uniform loads scalar (s_load) although the loop
     // contains volatile asm
     using const_u32 = const __attribute__((address_space(4))) unsigned;
-    const_u32* off32 = (const_u32*)(size_t)(a.s2off + c_begin);
-    // LDS byte address of this lane's slot in the column of the wave's first round; one column
-    // (8 bytes) further per round
-    unsigned lane_addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds + (unsigned)lane * 8u +
-                         (unsigned)((c_begin - chunk_c0) >> 5) * 8u;
-
-    // the row offsets of a round are fetched one round ahead, the LDS slots one char ahead;
-    // the last prefetches of a wave run past its range into valid padding and are never used
-    unsigned rowoff[kUnroll], rowoff_next[kUnroll];
-#pragma unroll
-    for (int q = 0; q < kUnroll; ++q) rowoff[q] = row_of(off32[q]);
-    SlotRegs cur;
-    lds_issue(cur, lane_addr + rowoff[0]);
-    lds_retire(cur);
-    for (int g = 0; g < a.wave_chars; g += kUnroll) {
-#pragma unroll
-        for (int q = 0; q < kUnroll; ++q) rowoff_next[q] = row_of(off32[g + kUnroll + q]);   // wave-uniform
-        count_round(cnt, cur, rowoff, rowoff_next[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
-#pragma unroll
-        for (int q = 0; q < kUnroll; ++q) rowoff[q] = rowoff_next[q];
-        lane_addr += 8u;
-    }
+    // (32-bit index arithmetic: a 64-bit multiply would go through the VALU and make these vector loads)
+    const int class_chars = __builtin_amdgcn_readfirstlane(a.class_chars);    // (loaded under a divergent branch above)
+    const int sym_at = __builtin_amdgcn_readfirstlane(((int)blockIdx.y * kClasses + (kClasses - kWaveClasses - low_class)) * class_chars);
+    const_u32* sym = (const_u32*)(size_t)(a.classes + sym_at);
+    const unsigned lane_base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds + (unsigned)lane * 8u;
+    count_classes(cnt, sym, kWaveClasses, class_chars, (unsigned)low_class, lane_base, lane, row_of);
 
     // ---- epilogue: sum the WAVES partial counters (bit-sliced ripple adds through LDS),
     // then expand the merged planes to integers and store them.
@@ -552,9 +622,9 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
         double pess = -INFINITY;
 #pragma unroll
         for (int e = 0; e < kPer; ++e) {
-            const int o = (int)blockIdx.x * kTile + o_local + e - a.lead;      // relative to the range's first offset
+            const int o = (int)blockIdx.x * kTileStride + o_local + e - a.lead;      // relative to the range's first offset
             up[e] = -INFINITY;
-            if (o >= 0 && o < a.span) {
+            if (o >= 0 && o < a.span && o_local + e < kTileStride) {
                 double pe;
                 offset_bounds(sel.bounds, (int)n[0][e], (int)n[1][e], (int)n[2][e], up[e], pe);
                 pess = fmax(pess, pe);
@@ -582,7 +652,7 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
             if (up[e] >= need) {
                 const int slot = atomicAdd(sel.cand_count, 1);
                 if (slot < a.cap) {
-                    sel.cand[slot] = a.first + (int)blockIdx.x * kTile + o_local + e - a.lead;
+                    sel.cand[slot] = a.first + (int)blockIdx.x * kTileStride + o_local + e - a.lead;
                     sel.cand_upper[slot] = up[e];
                 }
             }
@@ -613,10 +683,10 @@ constexpr int kScalCountOffset = 8;        // cand_count inside them
 struct DuoArgs {
     const unsigned char* s1;
     const unsigned*      symbol_planes;
-    const unsigned*      s2off;        // symbols of the launch's first query; query q at + q * s2_stride
+    const unsigned*      classes;      // class-ordered symbols of the launch's first query; query q at + q * s2_stride
     size_t               s2_stride;    // in elements
     int base;             // first offset of tile 0 (multiple of 32)
-    int wave_chars;       // chars per wave (multiple of kUnroll, <= kDuoMaxWaveChars); 8 waves cover the query
+    int class_chars;      // chars per shift class (multiple of kUnroll); a wave walks 4 classes (<= kDuoMaxWaveChars chars)
     int lds_slots;        // slots per staged row
     int nq;               // queries of this launch
     int nmodes;
@@ -661,10 +731,10 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
     const int group = wave >> 3;
     const int gw = wave & 7;                         // wave inside its group
     const int gtid = tid & (kDuoGroupWaves * 64 - 1);
-    const int tile_o0 = a.base + blockIdx.x * kTile;
+    const int tile_o0 = a.base + blockIdx.x * kTileStride;
     const int slot0 = tile_o0 >> 5;
 
-    // ---- planes of the window [tile_o0, +kTile+m): as psa_count_kernel<16>
+    // ---- planes of the window [tile_o0, +kTile+32*class_chars): as psa_count_kernel<16>
     {
         constexpr int kHalf = 512;
         const int hi_half = tid >= kHalf ? 1 : 0;
@@ -727,23 +797,13 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
         for (int w = 0; w < 2; ++w)
 #pragma unroll
             for (int k = 0; k < kCounters; ++k) cnt[w][k].clear();
-        const int c_begin = gw * a.wave_chars;
-        const_u32* off32 = (const_u32*)(size_t)(a.s2off + (size_t)q * a.s2_stride + c_begin);
-        unsigned lane_addr = lds_base + (unsigned)lane * 8u + (unsigned)(c_begin >> 5) * 8u;
-        unsigned rowoff[kUnroll], rowoff_next[kUnroll];
-#pragma unroll
-        for (int i = 0; i < kUnroll; ++i) rowoff[i] = off32[i];
-        SlotRegs cur;
-        lds_issue(cur, lane_addr + rowoff[0]);
-        lds_retire(cur);
-        for (int g = 0; g < a.wave_chars; g += kUnroll) {
-#pragma unroll
-            for (int i = 0; i < kUnroll; ++i) rowoff_next[i] = off32[g + kUnroll + i];
-            count_round(cnt, cur, rowoff, rowoff_next[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
-#pragma unroll
-            for (int i = 0; i < kUnroll; ++i) rowoff[i] = rowoff_next[i];
-            lane_addr += 8u;
-        }
+        constexpr int kWaveClasses = kClasses / kDuoGroupWaves;
+        const int low_class = gw * kWaveClasses;
+        const int class_chars = __builtin_amdgcn_readfirstlane(a.class_chars);
+        const int sym_at = __builtin_amdgcn_readfirstlane((kClasses - kWaveClasses - low_class) * class_chars);   // scalar unit
+        const_u32* sym = (const_u32*)(size_t)(a.classes + (size_t)q * a.s2_stride + sym_at);
+        count_classes(cnt, sym, kWaveClasses, class_chars, (unsigned)low_class, lds_base + (unsigned)lane * 8u, lane,
+                      [](unsigned sym_off) { return sym_off; });
 
         PSA_DPHASE(1);
         // the epilogue is a chain of short, latency-bound steps: let its instructions pass the other group's main loop
@@ -833,9 +893,9 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
             double pess = -INFINITY;
 #pragma unroll
             for (int e = 0; e < kDuoPer; ++e) {
-                const int o = (int)blockIdx.x * kTile + o_local + e - a.lead;
+                const int o = (int)blockIdx.x * kTileStride + o_local + e - a.lead;
                 up[e] = -INFINITY;
-                if (o >= 0 && o < a.span) {
+                if (o >= 0 && o < a.span && o_local + e < kTileStride) {
                     double pe;
                     offset_bounds(sel.bounds, (int)n[0][e], (int)n[1][e], (int)n[2][e], up[e], pe);
                     pess = fmax(pess, pe);
@@ -862,7 +922,7 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
                 if (up[e] >= need) {
                     const int slot = atomicAdd(cand_count, 1);
                     if (slot < a.cap) {
-                        cand[slot] = a.first + (int)blockIdx.x * kTile + o_local + e - a.lead;
+                        cand[slot] = a.first + (int)blockIdx.x * kTileStride + o_local + e - a.lead;
                         cand_upper[slot] = up[e];
                     }
                 }
