@@ -708,12 +708,6 @@ psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last,
 }
 
 // ---- filter engine -------------------------------------------------------------
-int exchange_bytes(int waves)
-{
-    // round 0 of the epilogue: waves/2 writers, 2*kCounters*kPlanes dwords per lane
-    return (waves / 2) * (2 * psa::kCounters * psa::kPlanes) * 64 * 4;
-}
-
 // Largest chunk count a Seq2 class buffer is sized for (every chunk rounds its classes up to whole rounds)
 constexpr int kMaxChunks = 24;
 static_assert((kMaxChunks + 1) * psa::kClasses * psa::kUnroll + psa::kUnroll <= kSeq2Slack, "class-order buffer");
@@ -721,7 +715,7 @@ static_assert((kMaxChunks + 1) * psa::kClasses * psa::kUnroll + psa::kUnroll <= 
 bool plan_filter(int first, int last, int m, FilterPlan* best)
 {
     const int ntiles = (last - (first & ~31) + psa::kTileStride - 1) / psa::kTileStride;
-    const int publish = psa::kCounters * psa::kMergedPlanes * 128 * 4;
+    const int cells = psa::kCellDwords * 4;              // the epilogue's count cells reuse the plane rows
     const int rounds_total = ((m + psa::kClasses - 1) / psa::kClasses + psa::kUnroll - 1) / psa::kUnroll;   // per class
     double best_cost = 0.0;
     bool found = false;
@@ -746,8 +740,7 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
             // 16 waves: rows 4 KiB apart (a symbol is its row offset); 8 waves: rows packed, two workgroups per CU
             const int row_slots = waves == 16 ? psa::kRowSlots : slots;
             int lds = psa::kMaskRows * row_slots * 8;
-            if (exchange_bytes(waves) > lds) lds = exchange_bytes(waves);
-            if (publish > lds) lds = publish;
+            if (cells > lds) lds = cells;
             if (lds > kLdsLimit) continue;
             // the count kernel needs ~120 VGPRs: 16 waves per CU
             int per_cu = kLdsLimit / lds;
@@ -872,9 +865,7 @@ bool duo_fits(int m, int* class_chars, int* lds_slots)
     const int rounds = ((m + psa::kClasses - 1) / psa::kClasses + psa::kUnroll - 1) / psa::kUnroll;
     const int cc = rounds * psa::kUnroll;
     const int slots = psa::kTile / 32 + cc + 1;
-    if ((psa::kClasses / psa::kDuoGroupWaves) * cc > psa::kDuoMaxWaveChars || slots > psa::kRowSlots ||
-        psa::kDuoLdsBytes > kLdsLimit)
-        return false;
+    if ((psa::kClasses / psa::kDuoGroupWaves) * cc > psa::kDuoMaxWaveChars || slots > psa::kRowSlots) return false;
     *class_chars = cc;
     *lds_slots = slots;
     return true;

@@ -45,7 +45,6 @@ constexpr int kUnroll = 32;        // chars per carry-save round (2^kLevels)
 constexpr int kLevels = 5;
 constexpr int kPlanes = 10;        // per-wave counters hold up to 1023 chars
 constexpr int kMaxWaveChars = 992; // multiple of kUnroll below 2^kPlanes
-constexpr int kMergedPlanes = 15;  // 16 waves x 1023 < 2^15
 constexpr int kMaskRows = 28;      // 27 symbols + the all-zero row of the padding symbol
 constexpr int kCounters = 3;       // n_lo, n_hi, n_both
 constexpr int kRowShift = 12;      // LDS rows of the count kernel are 4096 bytes apart (512 slots)
@@ -332,6 +331,69 @@ __device__ __forceinline__ void count_classes(Counter (&cnt)[2][kCounters],
     if (low_class) shift_planes(cnt, low_class, lane);
 }
 
+// ---- counter planes -> integer counts, summed over the waves in LDS ----------------
+// cells[counter][t][word] (dwords): bits 0-15 = the count of position 32*word + t, bits 16-31 that of
+// position 32*word + 16 + t.  A workgroup's counts stay below 2^16 (at most 16 x 1023 or 8 x 2047 chars),
+// so the two halves never carry into each other.
+constexpr int kTileWords = kTile / 32;
+constexpr int kCellDwords = kCounters * 16 * kTileWords;
+
+// 16 plane words (planes 0..15 of 32 positions) -> 16 dwords, dword t = count(t) | count(t+16) << 16:
+// the lower four stages of the 32x32 bit-matrix transpose (Hacker's Delight 7-3), applied to both
+// 16-bit halves at once
+__device__ __forceinline__ void planes_to_counts(unsigned (&a)[16])
+{
+    unsigned m = 0x00ff00ffu;
+#pragma unroll
+    for (int j = 8; j != 0; j >>= 1, m ^= (m << j)) {
+#pragma unroll
+        for (int k = 0; k < 16; k = (k + j + 1) & ~j) {
+            const unsigned t = ((a[k] >> j) ^ a[k + j]) & m;
+            a[k] ^= t << j;
+            a[k + j] ^= t;
+        }
+    }
+}
+
+// `words` = words per row of the cell array (kTileWords, or kTileWords - 1 where the unused last word is
+// not stored); `all_words` = false skips lane 63's second word (word 127)
+template <typename Counter>
+__device__ __forceinline__ void add_counts_to_cells(Counter (&cnt)[2][kCounters], unsigned* cells, int words,
+                                                    int lane, bool all_words)
+{
+    constexpr int kHave = (int)(sizeof(cnt[0][0].plane) / sizeof(unsigned));
+    static_assert(kHave <= 16, "a wave's counts fit 16 bits");
+#pragma unroll
+    for (int w = 0; w < 2; ++w) {
+        const int word = w * 64 + lane;
+        if (!all_words && word >= words) continue;
+#pragma unroll
+        for (int k = 0; k < kCounters; ++k) {
+            unsigned v[16];
+#pragma unroll
+            for (int p = 0; p < 16; ++p) v[p] = p < kHave ? cnt[w][k].plane[p] : 0u;
+            planes_to_counts(v);
+#pragma unroll
+            for (int t = 0; t < 16; ++t)
+                __hip_atomic_fetch_add(cells + (k * 16 + t) * words + word, v[t], __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+}
+
+// counts of the PER consecutive positions starting at o_local (PER divides 16: one word, one half)
+template <int PER>
+__device__ __forceinline__ void read_cells(unsigned (&n)[kCounters][PER], const unsigned* cells, int words, int o_local)
+{
+    const int word = o_local >> 5;
+    const int t0 = o_local & 15;
+    const unsigned sh = (unsigned)(o_local & 16);
+#pragma unroll
+    for (int k = 0; k < kCounters; ++k)
+#pragma unroll
+        for (int e = 0; e < PER; ++e) n[k][e] = word < words ? (cells[(k * 16 + t0 + e) * words + word] >> sh) & 0xffffu : 0u;
+}
+
 // ---- score interval of one offset from its exact counts ------------------------
 struct BoundParams {
     double w[4];
@@ -487,94 +549,25 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     const unsigned lane_base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds + (unsigned)lane * 8u;
     count_classes(cnt, sym, kWaveClasses, class_chars, (unsigned)low_class, lane_base, lane, row_of);
 
-    // ---- epilogue: sum the WAVES partial counters (bit-sliced ripple adds through LDS),
-    // then expand the merged planes to integers and store them.
+    // ---- epilogue: every wave turns its counter planes into integers (bit-matrix transpose in
+    // registers, two 16-bit counts per dword) and adds them to the tile's cells in LDS (ds_add_u32);
+    // each thread then picks up the counts of its offsets.
     PSA_PHASE(2);
     __syncthreads();                                 // rows no longer needed: LDS is scratch now
     PSA_PHASE(3);
-    unsigned* scratch = reinterpret_cast<unsigned*>(lds);
-    // merged[word][counter][plane]: grows by one plane per round
-    unsigned merged[2][kCounters][kMergedPlanes];
-#pragma unroll
-    for (int w = 0; w < 2; ++w)
-#pragma unroll
-        for (int k = 0; k < kCounters; ++k)
-#pragma unroll
-            for (int p = 0; p < kMergedPlanes; ++p) merged[w][k][p] = p < kPlanes ? cnt[w][k].plane[p] : 0u;
-
-    // Round r: the upper half of the surviving waves hands its counters (kPlanes + r
-    // planes each) to the lower half, which adds them with a bit-sliced ripple adder.
-    {
-        int r = 0;
-#pragma unroll
-        for (int half = WAVES / 2; half >= 1; half >>= 1, ++r) {
-            const int np = kPlanes + r;                 // planes in flight this round
-            const int rec = 2 * kCounters * np;         // dwords per lane in the exchange buffer
-            if (wave >= half && wave < 2 * half) {
-                unsigned* dst = scratch + (size_t)(wave - half) * rec * 64 + lane;
-#pragma unroll
-                for (int w = 0; w < 2; ++w)
-#pragma unroll
-                    for (int k = 0; k < kCounters; ++k)
-#pragma unroll
-                        for (int p = 0; p < kMergedPlanes; ++p)
-                            if (p < np) dst[((w * kCounters + k) * np + p) * 64] = merged[w][k][p];
-            }
-            __syncthreads();
-            if (wave < half) {
-                const unsigned* src = scratch + (size_t)wave * rec * 64 + lane;
-#pragma unroll
-                for (int w = 0; w < 2; ++w)
-#pragma unroll
-                    for (int k = 0; k < kCounters; ++k) {
-                        unsigned carry = 0u;
-#pragma unroll
-                        for (int p = 0; p < kMergedPlanes; ++p)
-                            if (p < np) {
-                                const unsigned other = src[((w * kCounters + k) * np + p) * 64];
-                                const unsigned x = merged[w][k][p];
-                                merged[w][k][p] = xor3(x, other, carry);
-                                carry = maj3(x, other, carry);
-                            } else if (p == np) {
-                                merged[w][k][p] = carry;
-                            }
-                    }
-            }
-            __syncthreads();
-        }
-    }
-
-    // wave 0 publishes the merged planes: layout [counter][plane][word(128)]
+    unsigned* cells = reinterpret_cast<unsigned*>(lds);
+    for (int i = tid; i < kCellDwords; i += WAVES * 64) cells[i] = 0u;
+    __syncthreads();
+    add_counts_to_cells(cnt, cells, kTileWords, lane, true);
     PSA_PHASE(4);
-    unsigned* pub = scratch;
-    if (wave == 0) {
-#pragma unroll
-        for (int w = 0; w < 2; ++w)
-#pragma unroll
-            for (int k = 0; k < kCounters; ++k)
-#pragma unroll
-                for (int p = 0; p < kMergedPlanes; ++p) pub[(k * kMergedPlanes + p) * 128 + w * 64 + lane] = merged[w][k][p];
-    }
     __syncthreads();
 
-    // expand: each thread handles kTile / (WAVES*64) consecutive offsets of one word
+    // each thread handles kTile / (WAVES*64) consecutive offsets of one word
     constexpr int kPer = kTile / (WAVES * 64);
-    static_assert(kPer >= 1 && 32 % kPer == 0, "tile/threads");
+    static_assert(kPer >= 1 && 16 % kPer == 0, "tile/threads");
     const int o_local = tid * kPer;
-    const int word = o_local >> 5;
-    const int bit0 = o_local & 31;
     unsigned n[kCounters][kPer];
-#pragma unroll
-    for (int k = 0; k < kCounters; ++k) {
-#pragma unroll
-        for (int e = 0; e < kPer; ++e) n[k][e] = 0u;
-#pragma unroll
-        for (int p = 0; p < kMergedPlanes; ++p) {
-            const unsigned v = pub[(k * kMergedPlanes + p) * 128 + word] >> bit0;
-#pragma unroll
-            for (int e = 0; e < kPer; ++e) n[k][e] |= ((v >> e) & 1u) << p;
-        }
-    }
+    read_cells<kPer>(n, cells, kTileWords, o_local);
     if (!a.inline_select || gridDim.y > 1) {
         unsigned long long* dst = a.partial + (size_t)blockIdx.y * a.span_pad + (size_t)blockIdx.x * kTile + o_local;
 #pragma unroll
@@ -614,10 +607,10 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
     }
     // the counts are final
     PSA_PHASE(5);
-    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(scratch);
+    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(cells);    // (every thread has read its cells)
     for (int mode = 0; mode < a.nmodes; ++mode) {
         const CountArgs::CountSelect& sel = a.sel[mode];
-        __syncthreads();                              // everyone is done reading `pub` / the previous mode's s_best
+        __syncthreads();                              // everyone is done reading the cells / the previous mode's s_best
         double up[kPer];
         double pess = -INFINITY;
 #pragma unroll
@@ -663,20 +656,22 @@ __global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
 // ---- duo count kernel (batches) ------------------------------------------------
 // One workgroup per tile handles SEVERAL queries of a batch.  The tile's class planes depend on
 // Seq1 only: they are built once and shared by two groups of 8 waves.  Group g takes queries
-// g, g+2, ...: main loop over all chars of its query (8 waves x wave_chars), then its own epilogue
-// (merge, expand, bounds, candidates) in its own scratch, synchronised by a group-local barrier (an
+// g, g+2, ...: main loop over all chars of its query (8 waves x 4 shift classes), then its own epilogue
+// (counts into its own LDS cells, bounds, candidates), synchronised by a group-local barrier (an
 // LDS counter; s_barrier would stop the other group too).  Group 1 starts one epilogue late, so
 // while one group runs the latency-bound epilogue the other keeps the VALUs busy with its main
 // loop — in psa_count_kernel those phases (about 15 % of the kernel) leave the CU idle.
 constexpr int kDuoGroupWaves = 8;
 constexpr int kDuoPlanes = 11;             // per-wave counters: up to 2047 chars
 constexpr int kDuoMaxWaveChars = 2016;     // multiple of kUnroll below 2^kDuoPlanes
-constexpr int kDuoMergedPlanes = 14;       // 8 x 2047 < 2^14
-constexpr int kDuoPer = kTile / (kDuoGroupWaves * 64);     // offsets expanded per thread
-// per group: round 0 of one counter's merge (4 writers x 2 words x 11 planes x 64 lanes) >= the published planes
-constexpr int kDuoScratchBytes = 4 * 2 * kDuoPlanes * 64 * 4;
-static_assert(kCounters * kDuoMergedPlanes * 128 * 4 <= kDuoScratchBytes, "published planes fit the group scratch");
+constexpr int kDuoPer = kTile / (kDuoGroupWaves * 64);     // offsets per thread in the epilogue
+// per group: the count cells of the 127 words a tile answers for (the planes take 112 of the CU's 160 KiB)
+constexpr int kDuoCellWords = kTileStride / 32;
+constexpr int kDuoCellDwords = kCounters * 16 * kDuoCellWords;
+constexpr int kDuoScratchBytes = kDuoCellDwords * 4;
+static_assert(kDuoGroupWaves * kDuoMaxWaveChars < 65536, "a group's counts fit 16 bits");
 constexpr int kDuoLdsBytes = kMaskRows * kRowSlots * 8 + 2 * kDuoScratchBytes;
+static_assert(kDuoLdsBytes + 256 <= 160 * 1024, "planes + two groups' cells + the kernel's static LDS fit one CU");
 constexpr int kScalStride = 16;            // bytes between the search scalars of consecutive queries (host: Scalars)
 constexpr int kScalCountOffset = 8;        // cand_count inside them
 
@@ -722,9 +717,10 @@ __device__ __forceinline__ void duo_barrier(unsigned* ctr, unsigned& target, int
 __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
 {
     extern __shared__ uint2 lds[];                  // [kMaskRows][kRowSlots] planes, then one scratch per group
-    __shared__ unsigned s_planes[64];
     __shared__ unsigned s_bar[2];
     __shared__ unsigned long long s_best[2][kDuoGroupWaves + 1];
+    // the symbol table of the plane build lives in the (not yet used) cells of group 0
+    unsigned* const s_planes = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + kMaskRows * kRowSlots * 8);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -760,10 +756,15 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
             slot = next;
         }
     }
+    __syncthreads();
+    {   // both groups' count cells start from zero
+        unsigned* z = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + kMaskRows * kRowSlots * 8);
+        for (int i = tid; i < 2 * kDuoCellDwords; i += 1024) z[i] = 0u;
+    }
     __syncthreads();                                 // the last workgroup-wide barrier: the groups part here
 
-    unsigned* const scratch = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + kMaskRows * kRowSlots * 8 +
-                                                          group * kDuoScratchBytes);
+    unsigned* const cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + kMaskRows * kRowSlots * 8 +
+                                                        group * kDuoScratchBytes);
     unsigned* const bar = &s_bar[group];
     unsigned bar_target = 0u;
     if (group == 1 && a.nq > 1) {
@@ -808,79 +809,16 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
         PSA_DPHASE(1);
         // the epilogue is a chain of short, latency-bound steps: let its instructions pass the other group's main loop
         __builtin_amdgcn_s_setprio(3);
-        // ---- merge the group's 8 partial counters, one counter per pass (the scratch holds one)
-        unsigned merged[2][kCounters][kDuoMergedPlanes];
-#pragma unroll
-        for (int w = 0; w < 2; ++w)
-#pragma unroll
-            for (int k = 0; k < kCounters; ++k)
-#pragma unroll
-                for (int p = 0; p < kDuoMergedPlanes; ++p) merged[w][k][p] = p < kDuoPlanes ? cnt[w][k].plane[p] : 0u;
-#pragma unroll
-        for (int k = 0; k < kCounters; ++k) {
-            int r = 0;
-#pragma unroll
-            for (int half = kDuoGroupWaves / 2; half >= 1; half >>= 1, ++r) {
-                const int np = kDuoPlanes + r;
-                const int rec = 2 * np;
-                if (gw >= half && gw < 2 * half) {
-                    unsigned* dst = scratch + (size_t)(gw - half) * rec * 64 + lane;
-#pragma unroll
-                    for (int w = 0; w < 2; ++w)
-#pragma unroll
-                        for (int p = 0; p < kDuoMergedPlanes; ++p)
-                            if (p < np) dst[(w * np + p) * 64] = merged[w][k][p];
-                }
-                duo_barrier(bar, bar_target, lane, a.bad);
-                if (gw < half) {
-                    const unsigned* src = scratch + (size_t)gw * rec * 64 + lane;
-#pragma unroll
-                    for (int w = 0; w < 2; ++w) {
-                        unsigned carry = 0u;
-#pragma unroll
-                        for (int p = 0; p < kDuoMergedPlanes; ++p)
-                            if (p < np) {
-                                const unsigned other = src[(w * np + p) * 64];
-                                const unsigned x = merged[w][k][p];
-                                merged[w][k][p] = xor3(x, other, carry);
-                                carry = maj3(x, other, carry);
-                            } else if (p == np) {
-                                merged[w][k][p] = carry;
-                            }
-                    }
-                }
-                duo_barrier(bar, bar_target, lane, a.bad);
-            }
-        }
-        PSA_DPHASE(2);
-        // wave 0 of the group publishes the merged planes: [counter][plane][word(128)]
-        if (gw == 0) {
-#pragma unroll
-            for (int w = 0; w < 2; ++w)
-#pragma unroll
-                for (int k = 0; k < kCounters; ++k)
-#pragma unroll
-                    for (int p = 0; p < kDuoMergedPlanes; ++p)
-                        scratch[(k * kDuoMergedPlanes + p) * 128 + w * 64 + lane] = merged[w][k][p];
-        }
+        // ---- every wave adds its counts to the group's cells; then each thread picks up its offsets'
+        // counts (kDuoPer consecutive offsets of one word) and the cells are zeroed for the next query
+        add_counts_to_cells(cnt, cells, kDuoCellWords, lane, false);
         duo_barrier(bar, bar_target, lane, a.bad);
-
-        // ---- expand: kDuoPer consecutive offsets of one word per thread
+        PSA_DPHASE(2);
         const int o_local = gtid * kDuoPer;
-        const int word = o_local >> 5;
-        const int bit0 = o_local & 31;
         unsigned n[kCounters][kDuoPer];
-#pragma unroll
-        for (int k = 0; k < kCounters; ++k) {
-#pragma unroll
-            for (int e = 0; e < kDuoPer; ++e) n[k][e] = 0u;
-#pragma unroll
-            for (int p = 0; p < kDuoMergedPlanes; ++p) {
-                const unsigned v = scratch[(k * kDuoMergedPlanes + p) * 128 + word] >> bit0;
-#pragma unroll
-                for (int e = 0; e < kDuoPer; ++e) n[k][e] |= ((v >> e) & 1u) << p;
-            }
-        }
+        read_cells<kDuoPer>(n, cells, kDuoCellWords, o_local);
+        duo_barrier(bar, bar_target, lane, a.bad);
+        for (int i = gtid; i < kDuoCellDwords; i += kDuoGroupWaves * 64) cells[i] = 0u;
         PSA_DPHASE(3);
         // ---- bounds, running best, candidates (per mode), as psa_count_kernel
         for (int mode = 0; mode < a.nmodes; ++mode) {

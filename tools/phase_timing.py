@@ -25,7 +25,7 @@ buf = (C.c_ulonglong * (1024 * 8))()
 lib.psa_debug_phase_ts.restype = C.c_int
 assert lib.psa_debug_phase_ts(buf) == 0
 ts = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
-nt = (n - m + 1 + 4095) // 4096 + 1
+nt = (n - m + 1 + 4063) // 4064 + 1
 ts = ts[:nt]
 ts = ts[ts[:, 0] > 0]
 t0 = ts[:, 0].min()
