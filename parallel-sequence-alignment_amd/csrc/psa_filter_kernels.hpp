@@ -72,10 +72,17 @@ __device__ __forceinline__ unsigned csa(unsigned& a, unsigned b, unsigned c)
 // One bit-sliced counter: planes[p] holds bit p of 32 independent counts.
 // Values are pushed one per char; level L keeps one pending input so that
 // every second arrival triggers a full adder whose carry moves up a level.
+// Above the tree there is one lazy level: rounds are walked in pairs, the carry of the first round
+// of a pair (weight 2^kLevels) is held and added together with the second round's by one more full
+// adder — one ripple through the upper planes per two rounds.  HOW says what a round does with its
+// carry: kHold (first of a pair), kJoin (second of a pair), kAlone (a class's odd last round).
+enum CarryUse { kHold = 0, kJoin = 1, kAlone = 2 };
+
 template <int PLANES>
 struct SlicedCounterT {
     unsigned plane[PLANES];
     unsigned pend[kLevels];
+    unsigned held;
 
     __device__ __forceinline__ void clear()
     {
@@ -83,29 +90,38 @@ struct SlicedCounterT {
         for (int p = 0; p < PLANES; ++p) plane[p] = 0u;
     }
 
+    // v of weight 2^P: ripple into the planes from P up (half adders)
+    template <int P>
+    __device__ __forceinline__ void ripple(unsigned v)
+    {
+#pragma unroll
+        for (int p = P; p < PLANES - 1; ++p) {
+            const unsigned c = plane[p] & v;
+            plane[p] ^= v;
+            v = c;
+        }
+        plane[PLANES - 1] ^= v;
+    }
+
     // T = index of the char inside the round, L = level (both compile-time so the
     // whole carry-save tree is straight-line code)
-    template <int L, int T>
+    template <int L, int T, int HOW>
     __device__ __forceinline__ void push_level(unsigned v)
     {
         if constexpr (L == kLevels) {
-            // one carry of weight 2^kLevels per round: ripple into the upper planes
-#pragma unroll
-            for (int p = kLevels; p < PLANES - 1; ++p) {
-                const unsigned c = plane[p] & v;
-                plane[p] ^= v;
-                v = c;
-            }
-            plane[PLANES - 1] ^= v;
+            // the round's one carry of weight 2^kLevels
+            if constexpr (HOW == kHold) held = v;
+            else if constexpr (HOW == kJoin) ripple<kLevels + 1>(csa(plane[kLevels], held, v));
+            else ripple<kLevels>(v);
         } else if constexpr ((T & 1) == 0) {
             pend[L] = v;
         } else {
-            push_level<L + 1, (T >> 1)>(csa(plane[L], pend[L], v));
+            push_level<L + 1, (T >> 1), HOW>(csa(plane[L], pend[L], v));
         }
     }
 
-    template <int T>
-    __device__ __forceinline__ void push(unsigned v) { push_level<0, T>(v); }
+    template <int T, int HOW>
+    __device__ __forceinline__ void push(unsigned v) { push_level<0, T, HOW>(v); }
 };
 using SlicedCounter = SlicedCounterT<kPlanes>;
 
@@ -234,21 +250,31 @@ struct SlotRegs {
 template <int IMM>
 __device__ __forceinline__ void lds_issue(SlotRegs& n, unsigned addr)
 {
+#ifdef PSA_EXP_NOLDS          // timing experiment only (wrong results): the loop without its LDS reads
+    n.v[0] = ((unsigned long long)addr << 32) | (addr * 3u);
+    n.v[1] = ~n.v[0];
+    asm volatile("" : "+v"(n.v[0]), "+v"(n.v[1]));
+#else
     asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4"
                  : "=&v"(n.v[0]), "=&v"(n.v[1])
                  : "v"(addr), "i"(IMM), "i"(IMM + 512));
+#endif
 }
 
 __device__ __forceinline__ void lds_retire(SlotRegs& n)
 {
+#ifdef PSA_EXP_NOWAIT         // timing experiment only (wrong results): never wait for the LDS
+    asm volatile("" : "+v"(n.v[0]), "+v"(n.v[1]));
+#else
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n.v[0]), "+v"(n.v[1]));
+#endif
 }
 
 // One char of a shift class: T is its index inside the round.  Char k of the class reads slot
 // l + k (word l) and l + 64 + k (word l+64) of its symbol's row: the round's base address moves
 // on by kUnroll slots per round, T is an immediate offset.  `cur` holds this char's slots; the
 // next char's are requested first (T == 31: char 0 of the next round).
-template <int T, typename Counter>
+template <int T, int HOW, typename Counter>
 __device__ __forceinline__ void class_step(Counter (&cnt)[2][kCounters], SlotRegs& cur,
                                            const unsigned (&rowoff)[kUnroll], unsigned next_rowoff,
                                            unsigned lane_addr)
@@ -259,22 +285,22 @@ __device__ __forceinline__ void class_step(Counter (&cnt)[2][kCounters], SlotReg
     else lds_issue<8 * kUnroll>(nxt, lane_addr + next_rowoff);
     const unsigned lo0 = (unsigned)cur.v[0], hi0 = (unsigned)(cur.v[0] >> 32);
     const unsigned lo1 = (unsigned)cur.v[1], hi1 = (unsigned)(cur.v[1] >> 32);
-    cnt[0][0].template push<T>(lo0);
-    cnt[0][1].template push<T>(hi0);
-    cnt[0][2].template push<T>(lo0 & hi0);
-    cnt[1][0].template push<T>(lo1);
-    cnt[1][1].template push<T>(hi1);
-    cnt[1][2].template push<T>(lo1 & hi1);
+    cnt[0][0].template push<T, HOW>(lo0);
+    cnt[0][1].template push<T, HOW>(hi0);
+    cnt[0][2].template push<T, HOW>(lo0 & hi0);
+    cnt[1][0].template push<T, HOW>(lo1);
+    cnt[1][1].template push<T, HOW>(hi1);
+    cnt[1][2].template push<T, HOW>(lo1 & hi1);
     lds_retire(nxt);
     cur = nxt;
 }
 
-template <typename Counter, int... Ts>
+template <int HOW, typename Counter, int... Ts>
 __device__ __forceinline__ void class_round(Counter (&cnt)[2][kCounters], SlotRegs& cur,
                                             const unsigned (&rowoff)[kUnroll], unsigned next_rowoff,
                                             unsigned lane_addr, std::integer_sequence<int, Ts...>)
 {
-    (class_step<Ts>(cnt, cur, rowoff, next_rowoff, lane_addr), ...);
+    (class_step<Ts, HOW>(cnt, cur, rowoff, next_rowoff, lane_addr), ...);
 }
 
 // Counter planes moved down by `s` bit positions (C[x] <- C[x + s], 1 <= s <= 31): word w takes
@@ -290,8 +316,9 @@ __device__ __forceinline__ void shift_planes(Counter (&cnt)[2][kCounters], unsig
 #pragma unroll
         for (int p = 0; p < (int)(sizeof(cnt[0][k].plane) / sizeof(unsigned)); ++p) {
             const unsigned a = cnt[0][k].plane[p], b = cnt[1][k].plane[p];
-            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(0, (int)a, 0x134, 0xf, 0xf, false);   // wave_rol:1:
-            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(0, (int)b, 0x134, 0xf, 0xf, false);   // lane l <- lane l+1
+            // wave_rol:1: lane l <- lane l+1 (every lane is written; `old` only spares a v_mov 0)
+            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)a, 0x134, 0xf, 0xf, false);
+            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)b, 0x134, 0xf, 0xf, false);
             cnt[0][k].plane[p] = __builtin_amdgcn_alignbit(last_lane ? rb : ra, a, s);
             cnt[1][k].plane[p] = __builtin_amdgcn_alignbit(rb, b, s);
         }
@@ -312,21 +339,29 @@ __device__ __forceinline__ void count_classes(Counter (&cnt)[2][kCounters],
     unsigned rowoff[kUnroll], rowoff_next[kUnroll];
 #pragma unroll
     for (int q = 0; q < kUnroll; ++q) rowoff[q] = row_of(sym[q]);
+    unsigned lane_addr;
+    SlotRegs cur;
+    // one round; `how` is what becomes of its carry (CarryUse)
+    auto round = [&](auto how) {
+        sym += kUnroll;
+#pragma unroll
+        for (int q = 0; q < kUnroll; ++q) rowoff_next[q] = row_of(sym[q]);   // wave-uniform
+        class_round<decltype(how)::value>(cnt, cur, rowoff, rowoff_next[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
+#pragma unroll
+        for (int q = 0; q < kUnroll; ++q) rowoff[q] = rowoff_next[q];
+        lane_addr += 8u * kUnroll;
+    };
     for (int c = 0; c < nclasses; ++c) {
         if (c) shift_planes(cnt, 1u, lane);              // Horner step: C[x] <- C[x+1], then add the next class
-        unsigned lane_addr = lane_base;
-        SlotRegs cur;
+        lane_addr = lane_base;
         lds_issue<0>(cur, lane_addr + rowoff[0]);
         lds_retire(cur);
-        for (int g = 0; g < class_chars; g += kUnroll) {
-            sym += kUnroll;
-#pragma unroll
-            for (int q = 0; q < kUnroll; ++q) rowoff_next[q] = row_of(sym[q]);   // wave-uniform
-            class_round(cnt, cur, rowoff, rowoff_next[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
-#pragma unroll
-            for (int q = 0; q < kUnroll; ++q) rowoff[q] = rowoff_next[q];
-            lane_addr += 8u * kUnroll;
+        int g = 0;
+        for (; g + 2 * kUnroll <= class_chars; g += 2 * kUnroll) {
+            round(std::integral_constant<int, kHold>{});
+            round(std::integral_constant<int, kJoin>{});
         }
+        if (g < class_chars) round(std::integral_constant<int, kAlone>{});
     }
     if (low_class) shift_planes(cnt, low_class, lane);
 }
@@ -479,7 +514,7 @@ __device__ unsigned long long g_phase_ts[1024][8];
 #endif
 
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void psa_count_kernel(CountArgs a)
+__global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
 {
     extern __shared__ uint2 lds[];                  // [kMaskRows][lds_slots]; reused by the epilogue
     const int tid = threadIdx.x;

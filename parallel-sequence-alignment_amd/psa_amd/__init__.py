@@ -181,7 +181,7 @@ class Context:
         self.n = self.m = None
 
     def close(self):
-        if getattr(self, "_h", None) and self._h.value:
+        if getattr(self, "_h", None) and self._h.value and lib is not None:      # (lib is None at interpreter exit)
             lib.psa_destroy(self._h)
             self._h = C.c_void_p()
 
