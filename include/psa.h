@@ -142,6 +142,13 @@ psa_status psa_scores(psa_context* ctx, int first_offset, int last_offset,
 psa_status psa_debug_counts(psa_context* ctx, int first_offset, int last_offset,
                             uint32_t* n_star, uint32_t* n_colon, uint32_t* n_dot);
 int psa_fallback_count(psa_context* ctx);
+/* Filter searches of this context whose candidate selection ran twice: candidates are picked
+ * against a running bound while the tiles finish; when that overflows the list, the selection
+ * is repeated against the final bound (only a second overflow goes to the sequential engine). */
+int psa_reselect_count(psa_context* ctx);
+/* Batches redone with the per-query count kernel because a wave-group barrier of the batch
+ * count kernel gave up (never expected on a healthy device). */
+int psa_duo_retry_count(psa_context* ctx);
 /* The filter engine's exact re-score (total + best delta, cpu_funcs.c:299) of
  * up to 2048 arbitrary offsets, without the filter in front of it. */
 psa_status psa_debug_rescore(psa_context* ctx, const int32_t* offsets, int count, double* scores);

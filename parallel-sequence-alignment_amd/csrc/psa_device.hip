@@ -384,6 +384,8 @@ struct psa_context {
     bool duo = true;                   // batches: one workgroup per tile serves several queries (psa_count_duo_kernel)
     int  duo_queries = 32;             // queries per launch of it
     int  duo_skew_ticks = 1300;        // 100 MHz ticks group 1 starts late (one epilogue)
+    bool duo_force_timeout = false;    // debug library only: the group barriers of the batch kernel give up at once
+    int  duo_retries = 0;              // batches redone without the batch kernel after a group barrier timed out
     bool granted_rescore = false;
     bool rescore_pad = true;
     bool        own_stream = false;
@@ -445,7 +447,8 @@ struct psa_context {
     double      sum_search_ms = 0.0, sum_kernel_ms = 0.0;   // over profiled searches since profiling was switched on
     int         profiled = 0;
     int         last_kernel_queries = 1;     // queries covered by the launch timed between ev[2] and ev[3]
-    int         fallbacks = 0;               // filter searches that overflowed into the sequential engine
+    int         fallbacks = 0;               // filter searches redone by the sequential engine
+    int         reselects = 0;               // filter searches whose selection ran twice (overflow against the running bound)
     int         seq = 0;                     // sequence number of the last search enqueued
 };
 
@@ -532,7 +535,7 @@ psa_status report_bad(psa_context* c)
     if (!bad) return PSA_OK;
     PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
     *c->h_bad = 0;
-    if (bad & 4) {
+    if (bad & 4) {      // (batches retry without the batch kernel first: psa_search_batch*)
         set_last_error("internal: a wave-group barrier of the batch count kernel timed out");
         return PSA_ERR_DEVICE;
     }
@@ -892,6 +895,7 @@ psa_status launch_count_duo(psa_context* c, const unsigned* s2cls, size_t s2_str
     a.lead = first - base;
     a.span = last - first;
     a.skew_ticks = (unsigned)c->duo_skew_ticks;
+    a.spin_limit = c->duo_force_timeout ? 0 : (1 << 21);
     a.bad = c->d_bad;
     for (int k = 0; k < 2; ++k) {
         const int src = k < nmodes ? k : 0;
@@ -998,7 +1002,11 @@ psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hi
             if (e == 0 && (bits << 1) != 0) ok = false;          // subnormal weight
             if (e > max_exp) max_exp = e;
         }
+#ifdef PSA_EXPERIMENT
         static const bool chain_only = std::getenv("PSA_RESCORE_CHAIN") != nullptr;   // experiment knob
+#else
+        constexpr bool chain_only = false;
+#endif
         r.fast_ok = ok && !chain_only;
         r.fast_min_exp = max_exp + 2;
     }
@@ -1152,6 +1160,9 @@ psa_status psa_create(int device, void* stream, psa_context** out)
         return PSA_OK;
     }();
     if (st != PSA_OK) { psa_destroy(c); return st; }
+#ifdef PSA_EXPERIMENT
+    // Experiment / fault-injection knobs: only in the debug library (libpsa_debug.so, -DPSA_EXPERIMENT);
+    // the product library reads no environment variable except PSA_DEVICE (legacy entry point).
     if (const char* r = std::getenv("PSA_SEQ_R")) c->forced_r = std::atoi(r);
     if (const char* r = std::getenv("PSA_BATCH_STREAMS")) c->batch_streams = std::atoi(r) >= 2 ? 2 : 1;
     if (const char* r = std::getenv("PSA_RESCORE_GRID")) c->batch_rescore_grid = std::max(1, std::min(1024, std::atoi(r)));
@@ -1159,6 +1170,8 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     if (const char* r = std::getenv("PSA_DUO")) c->duo = std::atoi(r) != 0;
     if (const char* r = std::getenv("PSA_DUO_QUERIES")) c->duo_queries = std::max(2, std::min(4096, std::atoi(r)));
     if (const char* r = std::getenv("PSA_DUO_SKEW")) c->duo_skew_ticks = std::max(0, std::atoi(r));
+    if (const char* r = std::getenv("PSA_DUO_FORCE_TIMEOUT")) c->duo_force_timeout = std::atoi(r) != 0;
+#endif
     *out = c;
     return PSA_OK;
 }
@@ -1308,14 +1321,26 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
     c->slot[0].scal_dirty = false;            // the search ran to its end: scalars are zero again
     *c->h_bad = c->h_tails[0].bad;
     PSA_TRY(report_bad(c));                   // device-resident sequences are validated here
-    // overflow: more near-tied offsets than the candidate list holds.  A tail that does not echo
-    // this search's number means no candidate workgroup ran (cannot happen for finite scores);
-    // both are answered by the sequential engine.
-    const bool stale = c->h_tails[0].seq != c->seq;
-    if (stale) c->slot[0].scal_dirty = true;
+    // overflow: the candidate list did not hold everything picked against the RUNNING bound.  The bound
+    // left in the search scalars is final now, so the selection runs once more against it; only if that
+    // overflows too (more true near-ties than the list holds, e.g. a homopolymer) every offset is scored
+    // in reference order by the sequential engine.  A tail that does not echo this search's number means
+    // no candidate workgroup ran (cannot happen for finite scores): sequential engine as well.
+    bool stale = c->h_tails[0].seq != c->seq;
+    if (c->pending_filter && c->h_tails[0].overflow && !stale) {
+        SearchSlot& s = c->slot[0];
+        c->reselects += 1;
+        c->seq += 1;
+        c->timing_valid = false;
+        FilterPlan plan;
+        PSA_TRY(plan_on_slot(s, c->pending_first, c->pending_last, c->stream, &plan));
+        PSA_TRY(launch_filter_front(c, s, plan, c->pending_first, c->pending_last, c->stream, false, primary_tables(c)));
+        PSA_TRY(launch_filter_back(c, s, (long long)(c->pending_last - c->pending_first) * s.m, c->stream, primary_tables(c)));
+        PSA_HIP(hipStreamSynchronize(c->stream));
+        stale = c->h_tails[0].seq != c->seq;
+    }
     if (c->pending_filter && (c->h_tails[0].overflow || stale)) {
-        // more near-tied offsets than the candidate list holds (e.g. a homopolymer):
-        // score every offset in reference order instead
+        c->slot[0].scal_dirty = true;             // the bound is still in the scalars
         c->fallbacks += 1;
         c->seq += 1;
         PSA_TRY(launch_sequential(c, c->slot[0], c->pending_first, c->pending_last, nullptr, nullptr, c->stream, primary_tables(c)));
@@ -1346,9 +1371,11 @@ psa_status psa_search(psa_context* c, int first, int last, psa_result* out)
 // both searches of a query share one count pass and differ only in bounds, candidates and
 // re-score.  Count kernels of consecutive queries alternate between two streams; the re-score
 // and read-back of every query run on a third.
-static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int m, size_t stride,
-                             int first, int last, psa_result* results0, psa_result* results1)
+static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int m, size_t stride,
+                             int first, int last, psa_result* results0, psa_result* results1,
+                             bool allow_duo, bool* duo_timed_out)
 {
+    *duo_timed_out = false;
     if (!c || !d_queries || !results0 || nq < 1 || stride < (size_t)m) {
         set_last_error("psa_search_batch: bad arguments");
         return PSA_ERR_ARG;
@@ -1428,7 +1455,8 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
         return v;
     };
     int duo_wc = 0, duo_slots = 0;
-    const bool duo = pooled && c->duo && nq >= 2 && plan.nchunks == 1 && plan.waves == 16 && duo_fits(m, &duo_wc, &duo_slots);
+    const bool duo = allow_duo && pooled && c->duo && nq >= 2 && plan.nchunks == 1 && plan.waves == 16 &&
+                     duo_fits(m, &duo_wc, &duo_slots);
     if (duo) {
         // several queries per count launch (two wave groups per tile share the planes and alternate between
         // main loop and epilogue); launches alternate between the two streams, the re-scores follow on the third
@@ -1508,12 +1536,35 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
     PSA_HIP(hipStreamSynchronize(c->stream));
     int bad = 0;
     for (int k = 0; k < nq * nmodes; ++k) bad |= c->h_tails[k].bad;
+    if (duo && (bad & 4)) {
+        // A group barrier of the batch kernel gave up (a hand-rolled LDS barrier with a spin limit: a wave was
+        // held back far beyond any healthy delay).  Its counts cannot be trusted: the caller runs the batch
+        // again with the per-query count kernel, whose barriers are the hardware's.
+        PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
+        PSA_HIP(hipStreamSynchronize(c->stream));
+        *c->h_bad = 0;
+        if (bad & 3) { *c->h_bad = bad & 3; return report_bad(c); }       // alphabet errors are real either way
+        *duo_timed_out = true;
+        return PSA_OK;
+    }
     *c->h_bad = bad;
     PSA_TRY(report_bad(c));
     for (int mode = 0; mode < nmodes; ++mode)
         for (int q = 0; q < nq; ++q) {
             const int k = mode * nq + q;
-            if (filter && (c->h_tails[k].overflow || c->h_tails[k].seq != seq_of(mode, q))) {
+            bool stale = filter && c->h_tails[k].seq != seq_of(mode, q);
+            if (pooled && c->h_tails[k].overflow && !stale) {
+                // overflow against the running bound: select once more against the final one (still in the
+                // query's pool entry), with the per-query count kernel
+                SearchSlot v = pool_view(mode, q);
+                c->reselects += 1;
+                c->seq += 1;
+                PSA_TRY(launch_filter_front(c, v, plan, first, last, c->stream, false, tables[mode]));
+                PSA_TRY(launch_filter_back(c, v, pairs, c->stream, tables[mode]));
+                PSA_HIP(hipStreamSynchronize(c->stream));
+                stale = c->h_tails[k].seq != c->seq;
+            }
+            if (filter && (c->h_tails[k].overflow || stale)) {
                 SearchSlot& s = c->slot[0];
                 c->fallbacks += 1;
                 c->seq += 1;
@@ -1533,6 +1584,16 @@ static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int 
         s.d_tail = c->hd_tails;
     }
     return PSA_OK;
+}
+
+static psa_status batch_impl(psa_context* c, const void* d_queries, int nq, int m, size_t stride,
+                             int first, int last, psa_result* results0, psa_result* results1)
+{
+    bool timed_out = false;
+    PSA_TRY(batch_once(c, d_queries, nq, m, stride, first, last, results0, results1, true, &timed_out));
+    if (!timed_out) return PSA_OK;
+    c->duo_retries += 1;
+    return batch_once(c, d_queries, nq, m, stride, first, last, results0, results1, false, &timed_out);
 }
 
 psa_status psa_search_batch_device(psa_context* c, const void* d_queries, int nq, int m, size_t stride,
@@ -1722,6 +1783,14 @@ int psa_last_kernel_queries(psa_context* c) { return c ? c->last_kernel_queries 
 // How many filter searches of this context overflowed the candidate list and
 // were redone by the sequential engine (tests; adversarial inputs only).
 int psa_fallback_count(psa_context* c) { return c ? c->fallbacks : 0; }
+
+// How many filter searches ran their candidate selection twice: the first pass picks against a running
+// bound and overflowed the list, the second against the final bound (tests).
+int psa_reselect_count(psa_context* c) { return c ? c->reselects : 0; }
+
+// Batches this context ran a second time without the batch count kernel because one of its wave-group
+// barriers timed out (never expected; the debug library can force it: PSA_DUO_FORCE_TIMEOUT).
+int psa_duo_retry_count(psa_context* c) { return c ? c->duo_retries : 0; }
 
 // ---------------------------------------------------------------------------
 // legacy drop-in (cuda_funcs.h:33)

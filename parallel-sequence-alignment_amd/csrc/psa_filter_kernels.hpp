@@ -723,7 +723,8 @@ struct DuoArgs {
     int cap;
     int first, lead, span;
     unsigned skew_ticks;  // 100 MHz ticks group 1 waits before its first query
-    int* bad;             // |= 4 if a group barrier timed out (never expected)
+    int spin_limit;       // polls a group barrier waits before it gives up (debug library: 0 forces the give-up path)
+    int* bad;             // |= 4 if a group barrier timed out (never expected): the host redoes the batch without this kernel
     struct Select {
         char*   scalars;      // search scalars of the launch's first query (kScalStride apart)
         int*    cand;         // candidate offsets, `cap` per query
@@ -733,7 +734,7 @@ struct DuoArgs {
 };
 
 // barrier of the 8 waves of one group: arrival counter in LDS, monotonic (target grows by 8 per barrier)
-__device__ __forceinline__ void duo_barrier(unsigned* ctr, unsigned& target, int lane, int* bad)
+__device__ __forceinline__ void duo_barrier(unsigned* ctr, unsigned& target, int lane, int* bad, int spin_limit)
 {
     target += (unsigned)kDuoGroupWaves;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // this wave's LDS traffic is complete
@@ -741,7 +742,7 @@ __device__ __forceinline__ void duo_barrier(unsigned* ctr, unsigned& target, int
     int spins = 0;
     while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - target) < 0) {
         __builtin_amdgcn_s_sleep(1);
-        if (++spins > (1 << 21)) {                                   // ~0.1 s: give up loudly instead of hanging
+        if (++spins > spin_limit) {                                  // 2^21 polls ~ 0.1 s: give up loudly instead of hanging
             if (lane == 0) atomicOr(bad, 4);
             break;
         }
@@ -847,12 +848,12 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
         // ---- every wave adds its counts to the group's cells; then each thread picks up its offsets'
         // counts (kDuoPer consecutive offsets of one word) and the cells are zeroed for the next query
         add_counts_to_cells(cnt, cells, kDuoCellWords, lane, false);
-        duo_barrier(bar, bar_target, lane, a.bad);
+        duo_barrier(bar, bar_target, lane, a.bad, a.spin_limit);
         PSA_DPHASE(2);
         const int o_local = gtid * kDuoPer;
         unsigned n[kCounters][kDuoPer];
         read_cells<kDuoPer>(n, cells, kDuoCellWords, o_local);
-        duo_barrier(bar, bar_target, lane, a.bad);
+        duo_barrier(bar, bar_target, lane, a.bad, a.spin_limit);
         for (int i = gtid; i < kDuoCellDwords; i += kDuoGroupWaves * 64) cells[i] = 0u;
         PSA_DPHASE(3);
         // ---- bounds, running best, candidates (per mode), as psa_count_kernel
@@ -880,15 +881,15 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
                 const unsigned long long other = __shfl_xor(key, d, 64);
                 key = other > key ? other : key;
             }
-            duo_barrier(bar, bar_target, lane, a.bad);          // the previous mode's s_best has been read
+            duo_barrier(bar, bar_target, lane, a.bad, a.spin_limit);          // the previous mode's s_best has been read
             if (lane == 0) s_best[group][gw] = key;
-            duo_barrier(bar, bar_target, lane, a.bad);
+            duo_barrier(bar, bar_target, lane, a.bad, a.spin_limit);
             if (gtid == 0) {
                 for (int w = 1; w < kDuoGroupWaves; ++w) key = s_best[group][w] > key ? s_best[group][w] : key;
                 const unsigned long long old = atomicMax(global_best, key);
                 s_best[group][kDuoGroupWaves] = old > key ? old : key;
             }
-            duo_barrier(bar, bar_target, lane, a.bad);
+            duo_barrier(bar, bar_target, lane, a.bad, a.spin_limit);
             const double need = key_order(s_best[group][kDuoGroupWaves]);
 #pragma unroll
             for (int e = 0; e < kDuoPer; ++e)
@@ -900,7 +901,7 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
                     }
                 }
         }
-        duo_barrier(bar, bar_target, lane, a.bad);              // the scratch is free for the next query
+        duo_barrier(bar, bar_target, lane, a.bad, a.spin_limit);              // the scratch is free for the next query
         PSA_DPHASE(4);
     }
 }
@@ -1019,10 +1020,26 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
 #define PSA_RPHASE(k) do { } while (0)
 #endif
     PSA_RPHASE(0);
-    int count = *a.cand_count;
-    if (count > a.cap) count = a.cap;
+    const int count = *a.cand_count;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    if (count > a.cap) {
+        // The candidate list overflowed: candidates were picked against a RUNNING best, so early tiles can
+        // contribute far more than survive.  Nothing is re-scored; the bound in global_best is final now and
+        // stays, the host runs the selection once more against it (only a second overflow — more true
+        // near-ties than the list holds — goes to the sequential engine).
+        if (blockIdx.x == 0 && tid == 0) {
+            psa_result r;
+            r.score = 0.0; r.offset = -1; r.char_offset = -1; r.ch = 0; r.shard = -1; r.pairs = a.pairs;
+            a.out->result = r;
+            a.out->bad = *a.bad;
+            a.out->overflow = 1;
+            a.out->seq = a.seq;
+            *a.cand_count = 0;
+            *a.done = 0;
+        }
+        return;
+    }
     if ((int)blockIdx.x >= count) return;
     for (int k = tid; k < kRow * kRow; k += kRescoreThreads) s_clsrank[k] = a.clsrank[k];
     __syncthreads();
@@ -1230,7 +1247,6 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     __syncthreads();
     if (s_last && tid < 64) {
         const bool is_max = a.is_max != 0;
-        const int total = *a.cand_count;
         double bs = is_max ? -INFINITY : INFINITY;
         int bo = INT_MAX, idx = -1;
         for (int k = lane; k < count; k += 64) {
@@ -1262,7 +1278,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
             r.pairs = a.pairs;
             a.out->result = r;
             a.out->bad = *a.bad;
-            a.out->overflow = total > a.cap ? 1 : 0;
+            a.out->overflow = 0;
             a.out->seq = a.seq;
             // leave the search scalars clean for the next search on this slot
             *a.cand_count = 0;

@@ -32,7 +32,7 @@ EXPORTED_SYMBOLS = (
     "psa_set_engine", "psa_search", "psa_search_async", "psa_search_wait", "psa_scores",
     "psa_search_batch", "psa_search_batch_device",
     "psa_search_batch_minmax", "psa_search_batch_minmax_device",
-    "psa_debug_counts", "psa_fallback_count", "psa_debug_rescore",
+    "psa_debug_counts", "psa_fallback_count", "psa_reselect_count", "psa_duo_retry_count", "psa_debug_rescore",
     "psa_fold", "psa_shard_range", "psa_build_tables",
     "psa_set_profiling", "psa_last_timing", "psa_profile_totals", "psa_last_kernel_queries",
     "psa_generate_sequence", "psa_last_error", "psa_version",
@@ -88,6 +88,8 @@ def _load() -> C.CDLL:
     lib.psa_search_batch_minmax_device.argtypes = [vp, vp, i, i, C.c_size_t, i, i, C.POINTER(Result), C.POINTER(Result)]
     lib.psa_debug_counts.argtypes = [vp, i, i, vp, vp, vp]
     lib.psa_fallback_count.argtypes = [vp]
+    lib.psa_reselect_count.argtypes = [vp]
+    lib.psa_duo_retry_count.argtypes = [vp]
     lib.psa_debug_rescore.argtypes = [vp, vp, i, vp]
     lib.psa_fold.argtypes = [C.POINTER(Result), i, i, C.POINTER(Result)]
     lib.psa_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
@@ -307,6 +309,14 @@ class Context:
 
     def fallback_count(self) -> int:
         return lib.psa_fallback_count(self._h)
+
+    def duo_retry_count(self) -> int:
+        """Batches redone without the batch count kernel after one of its group barriers timed out."""
+        return lib.psa_duo_retry_count(self._h)
+
+    def reselect_count(self) -> int:
+        """Searches whose candidate selection ran twice (overflow against the running bound)."""
+        return lib.psa_reselect_count(self._h)
 
     def set_profiling(self, on: bool):
         _check(lib.psa_set_profiling(self._h, int(on)))

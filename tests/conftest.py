@@ -38,6 +38,29 @@ def psa():
 
 
 @pytest.fixture(scope="session")
+def psa_debug(psa):
+    """A second instance of the binding on libpsa_debug.so (-DPSA_EXPERIMENT): the only build that reads the
+    experiment / fault-injection environment knobs (PSA_SEQ_R, PSA_DUO_FORCE_TIMEOUT, ...)."""
+    import importlib.util
+    lib_path = os.path.join(PKG, "psa_amd", "libpsa_debug.so")
+    if not os.path.exists(lib_path):
+        import __graft_entry__
+        __graft_entry__.build()
+    old = os.environ.get("PSA_AMD_LIB")
+    os.environ["PSA_AMD_LIB"] = lib_path
+    try:
+        spec = importlib.util.spec_from_file_location("psa_amd_debug", os.path.join(PKG, "psa_amd", "__init__.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        if old is None:
+            del os.environ["PSA_AMD_LIB"]
+        else:
+            os.environ["PSA_AMD_LIB"] = old
+    return mod
+
+
+@pytest.fixture(scope="session")
 def reference_records(oracle):
     """The 15 stacked records of the reference's input.txt (tests/golden copy)."""
     return oracle.read_records(os.path.join(GOLDEN, "reference_input.txt"))

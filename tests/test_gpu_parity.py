@@ -151,8 +151,9 @@ def test_sub_ranges_and_shard_fold(ctx, oracle, psa):
 
 
 @pytest.mark.parametrize("r", [1, 2, 4])
-def test_lane_tile_variants(psa, oracle, reference_records, r, monkeypatch):
-    """The R-offsets-per-lane variants of the sequential kernel agree (PSA_SEQ_R)."""
+def test_lane_tile_variants(psa_debug, oracle, reference_records, r, monkeypatch):
+    """The R-offsets-per-lane variants of the sequential kernel agree (PSA_SEQ_R: a knob of the debug library)."""
+    psa = psa_debug
     monkeypatch.setenv("PSA_SEQ_R", str(r))
     w, s1, s2, is_max = reference_records[5]
     with psa.Context(0) as c:
@@ -355,6 +356,71 @@ def test_filter_engine_adversarial_and_fallback(psa, oracle):
                 assert (res.offset, res.char_offset, chr(res.ch)) == want[1:], (name, is_max)
                 assert res.score == want[0], (name, is_max)
         assert c.fallback_count() >= 2          # the two homopolymer cases, both modes
+
+
+def _planted_in_periodic(psa, n=60000, m=1000, at=52000):
+    """Seq1 = a two-letter period (every offset of one parity has the same counts: thousands of exact ties at a
+    mediocre score) with one exact copy of Seq2 planted near the end.  The tiles finish concurrently, so tiles
+    of the flat part pick their candidates against a running bound that does not know the planted copy yet and
+    overflow the 2048-entry list; against the final bound only the planted neighbourhood survives."""
+    s2 = psa.generate_sequence(4242, m)
+    s1 = bytearray(b"QW" * (n // 2))
+    s1[at:at + m] = s2
+    return bytes(s1), s2
+
+
+def test_overflow_against_running_bound_is_reselected_not_sequential(psa, oracle):
+    """VERDICT r1 'overflow cliff': a non-degenerate input whose early tiles are weak stays on the filter engine
+    (selection repeated against the final bound) and still returns the oracle's answer (cuda_funcs.cu:290-307
+    order)."""
+    s1, s2 = _planted_in_periodic(psa)
+    w = [1.5, 2.6, 0.3, 0.2]
+    want = oracle.search(s1, s2, w, True, threads=8)
+    other = psa.generate_sequence(4243, len(s2))
+    want_other = oracle.search(s1, other, w, True, threads=8)
+    reselected = 0
+    for attempt in range(3):                      # which tile publishes its bound first is a race: see it at least once
+        with psa.Context(0) as c:
+            c.set_engine(psa.ENGINE_FILTER)
+            res = run(c, s1, s2, w, True)
+            assert_same(res, want)
+            # the same through a batch (duo kernel): query 0 = the planted Seq2, query 1 = an unrelated one
+            got = c.search_batch([s2, other])
+            assert_same(got[0], want)
+            assert_same(got[1], want_other)
+            assert c.fallback_count() == 0
+            reselected += c.reselect_count()
+    assert reselected >= 1
+
+
+def test_batch_kernel_barrier_timeout_is_retried(psa_debug, oracle, monkeypatch):
+    """The hand-rolled wave-group barrier of the batch count kernel gives up after a spin limit.
+    The debug library forces that path: the batch must come back with the oracle's answers through the
+    per-query count kernel instead of failing with PSA_ERR_DEVICE."""
+    psa = psa_debug
+    monkeypatch.setenv("PSA_DUO_FORCE_TIMEOUT", "1")
+    s1 = psa.generate_sequence(51, 30000)
+    qs = [psa.generate_sequence(52 + q, 1200) for q in range(5)]
+    with psa.Context(0) as c:
+        c.set_engine(psa.ENGINE_FILTER)
+        c.set_weights(W_README, True)
+        c.set_seq1(s1)
+        got = c.search_batch(qs)
+        assert c.duo_retry_count() == 1
+        hi, lo = c.search_batch_minmax(qs)
+        assert c.duo_retry_count() == 2
+    for q, s2 in enumerate(qs):
+        assert_same(got[q], oracle.search(s1, s2, W_README, True, threads=8))
+        assert_same(hi[q], oracle.search(s1, s2, W_README, True, threads=8))
+        assert_same(lo[q], oracle.search(s1, s2, W_README, False, threads=8))
+    monkeypatch.delenv("PSA_DUO_FORCE_TIMEOUT")
+    with psa.Context(0) as c:                    # without the knob the batch kernel is not retried
+        c.set_engine(psa.ENGINE_FILTER)
+        c.set_weights(W_README, True)
+        c.set_seq1(s1)
+        again = c.search_batch(qs)
+        assert c.duo_retry_count() == 0
+    assert [r.as_tuple() for r in again] == [r.as_tuple() for r in got]
 
 
 def test_filter_engine_synthetic_golden_and_ranges(psa, oracle):
