@@ -6,28 +6,38 @@ Metric (BASELINE.json): char-pair scores/sec, whole job, on synthetic
 library's seeded generator, weights 1.5 2.6 0.3 0.2).
 
 A step is one pass of the hot path over one batch: Q independent Seq2 queries
-(default 256 as in BASELINE.json configs[4], seeds 2002+q) against the same Seq1 (seed 1002) — every offset of
-every query scored, every best mutant known on the host.  The step starts
-from the raw ASCII sequences resident in HBM, so symbol encoding and the Seq1
-class-plane build are inside the timed region.  Query 0 is BASELINE.json
-configs[2]; its answer is checked against the committed oracle golden by the
-tests (offset 870261, score -3265.7999999995977).
+(default 256 as in BASELINE.json configs[4], seeds 2002+q) against the same Seq1
+(seed 1002) — every offset of every query scored, every best mutant known on the
+host.  The step starts from the raw ASCII sequences resident in HBM, so symbol
+encoding is inside the timed region (`batch_from_host` reports the same step
+handed over as pageable HOST buffers, PCIe included; it is never `value`).
+Query 0 is BASELINE.json configs[2]; the run checks its MAX and MIN answers
+against the committed oracle goldens and exits non-zero on any mismatch
+(`verified`).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N>1 (total work fixed => "scaling": "strong"): the Q queries are dealt to the
-ranks in contiguous blocks (BASELINE.json configs[4] sharding: by query, no
-halo), each rank searches all offsets for its queries, and ONE RCCL
-all-reduce(sum) per step of a one-hot [Q,4] int64 buffer leaves all Q 32-byte
-records on every rank.  `--mode shard` runs configs[3] instead: one query,
-offsets split like the reference's MPI ranks (cpu_funcs.c:128-133), one
-all-reduce of the per-rank records, fold with the is_swapable order
-(cpu_funcs.c:71-94 replaced by one collective).
+`--gpus N` with N > 1 launches N ranks itself (one per GPU, torch.distributed.run
+on 127.0.0.1) BEFORE anything touches the GPU, unless it already runs under a
+launcher (WORLD_SIZE set): `python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N` works the same.  It exits non-zero if fewer than N devices
+are visible or the world size differs from N.
+
+N > 1, default `--scaling weak`: every rank searches its own Q queries (seeds
+continue per rank; per-GPU work fixed), no data-path collective; ONE RCCL
+all-reduce(sum) per step of a one-hot [N*Q,4] int64 buffer leaves all 32-byte
+records on every rank (the argmax exchange of north_star).  `--scaling strong`
+deals the Q queries of configs[4] to the ranks instead.  `--mode shard` runs
+configs[3]: one query, offsets split like the reference's MPI ranks
+(cpu_funcs.c:128-133), one all-reduce of the per-rank records, fold with the
+is_swapable order (cpu_funcs.c:71-94 replaced by one collective).
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -39,13 +49,59 @@ for p in (ROOT, PKG):
 
 WEIGHTS = [1.5, 2.6, 0.3, 0.2]          # README.md:57
 HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+VALU_PEAK = 1024 * 2.4e9 / 2            # wave64 instructions/s: 1024 SIMDs, one full-rate VALU op per 2 cycles at 2.4 GHz
 BYTES_PER_PAIR = 2                      # 1 B of Seq1 + 1 B of Seq2 per char pair
 SEED_SEQ1, SEED_QUERY0 = 1002, 2002
 
 
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--m", type=int, default=10_000)
+    ap.add_argument("--queries", type=int, default=256, help="Seq2 queries per step (batch mode)")
+    ap.add_argument("--mode", choices=("batch", "shard"), default="batch")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1, batch mode: weak = Q queries per rank, strong = Q queries dealt to the ranks")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="analysis only: time rank 0's share of a W-rank strong-scaling run on one GPU (no collective)")
+    ap.add_argument("--stub-search", action="store_true",
+                    help="launcher / exchange rehearsal without a GPU: gloo, records made up from the query index")
+    return ap.parse_args(argv)
+
+
+# --------------------------------------------------------------------------------------
+# launcher: --gpus N without a launcher around us
+# --------------------------------------------------------------------------------------
+def self_launch(args):
+    """Start N rank processes (torch.distributed.run, one node, 127.0.0.1) and return their exit code.
+    Nothing in this process has touched the GPU: torch.cuda.device_count() only counts."""
+    if not args.stub_search:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) visible", file=sys.stderr)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL)
+    return subprocess.run(cmd, env=env).returncode
+
+
+# --------------------------------------------------------------------------------------
+# record exchange (the only collective): one all-reduce(sum) of a one-hot buffer
+# --------------------------------------------------------------------------------------
 def gather_records(psa, dist, torch, mine, first_slot, total_slots, device):
-    """One collective: every rank writes its 32-byte records into its own rows of a
-    zeroed [total_slots,4] int64 buffer; the all-reduce(sum) is the gather of all records."""
+    """Every rank writes its 32-byte records into its own rows of a zeroed [total_slots,4] int64 buffer; the
+    all-reduce(sum) is the gather of all records."""
     buf = torch.zeros((total_slots, 4), dtype=torch.int64, device=device)
     if mine:
         rows = torch.frombuffer(bytearray(b"".join(bytes(r) for r in mine)), dtype=torch.int64).view(len(mine), 4)
@@ -110,32 +166,79 @@ def cpu_baseline(s1, s2, total, m, budget_s=9.0, threads=None):
             "sample": f"offsets [0,{sample}) of query 0 (1M x 10k MAX), {cores} OpenMP threads, {dt:.2f} s"}
 
 
+def latest_profile(pattern):
+    """The newest committed rocprofv3 summary of that kind (profiles/rNN_*)."""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)))
+    return files[-1] if files else None
+
+
+def golden_case(name):
+    path = os.path.join(ROOT, "tests", "golden", "synthetic_golden.json")
+    for c in json.load(open(path))["cases"]:
+        if c["name"] == name:
+            return c
+    return None
+
+
+def matches_golden(res, g):
+    return (res.offset, res.char_offset, chr(res.ch) if res.ch else "", "%.17g" % res.score) == \
+           (g["offset"], g["char_offset"], g["ch"], g["score"])
+
+
+def stub_main(args, world, rank):
+    """Launcher / exchange rehearsal on CPU (tests): gloo, no library compute — every rank makes up the records of
+    its queries from the query index, the real exchange code gathers them, rank 0 prints the one JSON line."""
+    import torch
+    import torch.distributed as dist
+    import psa_amd as psa
+    if world > 1:
+        dist.init_process_group("gloo")
+    nq = args.queries
+    per_rank = nq if args.scaling == "weak" else None
+    total_q = nq * world if args.scaling == "weak" else nq
+    lo, hi = (rank * nq, (rank + 1) * nq) if per_rank else query_block(nq, world, rank)
+    mine = []
+    for q in range(lo, hi):
+        r = psa.Result()
+        r.score, r.offset, r.char_offset, r.ch, r.shard, r.pairs = -1.5 * q, 7 * q + 1, q % 11, 65 + q % 26, q, 1000 + q
+        mine.append(r)
+    t0 = time.perf_counter()
+    recs = gather_records(psa, dist, torch, mine, lo, total_q, torch.device("cpu")) if world > 1 else mine
+    elapsed = time.perf_counter() - t0
+    ok = all((r.offset, r.shard, r.pairs) == (7 * q + 1, q, 1000 + q) and r.score == -1.5 * q for q, r in enumerate(recs))
+    if rank == 0:
+        print(json.dumps({"metric": "stub (launcher rehearsal, no search)", "value": 0.0, "unit": "char-pair scores/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed,
+                          "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+                          "data": "stub", "config": {"workload": "stub", "records": len(recs)},
+                          "verified": {"exchange": bool(ok)}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000)
-    ap.add_argument("--m", type=int, default=10_000)
-    ap.add_argument("--queries", type=int, default=256, help="Seq2 queries per step (batch mode)")
-    ap.add_argument("--mode", choices=("batch", "shard"), default="batch")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--engine", type=int, default=0)
-    ap.add_argument("--emulate-world", type=int, default=0,
-                    help="analysis only: time rank 0's share of a W-rank run on one GPU (no collective)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would misreport n_gpus")
+    if args.stub_search:
+        raise SystemExit(stub_main(args, world, rank))
 
     import numpy as np
     import torch
     import psa_amd as psa
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -145,13 +248,16 @@ def main():
     torch.cuda.set_device(device)
 
     n, m = args.n, args.m
-    nq = args.queries if args.mode == "batch" else 1
     total = n - m + 1
     emulated = args.emulate_world > 1 and world == 1
+    weak = args.mode == "batch" and args.scaling == "weak" and not emulated
     eff_world = args.emulate_world if emulated else world
     eff_rank = 0 if emulated else rank
+    # queries this rank holds: weak = its own Q (seeds continue across ranks), strong = all Q (it searches a block)
+    nq = args.queries if args.mode == "batch" else 1
+    seed0 = SEED_QUERY0 + (rank * nq if weak else 0)
     s1 = psa.generate_sequence_np(SEED_SEQ1, n)
-    queries = np.stack([psa.generate_sequence_np(SEED_QUERY0 + q, m) for q in range(nq)])
+    queries = np.stack([psa.generate_sequence_np(seed0 + q, m) for q in range(nq)])
     t1 = torch.from_numpy(s1).to(device)          # inputs resident in HBM before the timed region
     tq = torch.from_numpy(queries).to(device)
 
@@ -161,15 +267,17 @@ def main():
     ctx.set_weights(WEIGHTS, True)
 
     if args.mode == "batch":
-        qlo, qhi = query_block(nq, eff_world, eff_rank)
+        qlo, qhi = (0, nq) if weak else query_block(nq, eff_world, eff_rank)
+        total_q = nq * world if weak else nq                      # records exchanged per step
+        slot0 = rank * nq if weak else qlo
         first, last = 0, total
-        pairs_step = (qhi - qlo if emulated else nq) * total * m
+        pairs_step = (qhi - qlo if emulated else total_q) * total * m
 
         def step():
-            ctx.set_seq1_device(t1.data_ptr(), n)          # from raw ASCII: encode + class planes, once per batch
+            ctx.set_seq1_device(t1.data_ptr(), n)          # from raw ASCII: encode, once per batch
             mine = ctx.search_batch_device(tq[qlo].data_ptr(), qhi - qlo, m, m) if qhi > qlo else []
             if world > 1:
-                return gather_records(psa, dist, torch, mine, qlo, nq, device)
+                return gather_records(psa, dist, torch, mine, slot0, total_q, device)
             return mine
     else:
         first, last = psa.shard_range(total, eff_world, eff_rank)
@@ -183,57 +291,64 @@ def main():
                 rec = exchange_and_fold(psa, dist, torch, rec, rank, world, True, device)
             return [rec]
 
+    def timed(fn, steps):
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = fn()
+        torch.cuda.synchronize(device)
+        if dist:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, out
+
     for _ in range(args.warmup):
         results = step()
-
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize(device)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        results = step()
-    torch.cuda.synchronize(device)
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, results = timed(step, args.steps)
     value = pairs_step * args.steps / elapsed
 
     # configs[4] asks for MIN+MAX: both searches of every query from one shared class-count pass
     # (psa_search_batch_minmax).  Reported beside the headline, which stays the MAX-only batch.
     minmax = None
+    mm = None
+    from_host = None
     if args.mode == "batch":
         def step_minmax():
             ctx.set_seq1_device(t1.data_ptr(), n)
             hi, lo = ctx.search_batch_minmax_device(tq[qlo].data_ptr(), qhi - qlo, m, m) if qhi > qlo else ([], [])
             if world > 1:
-                both = gather_records(psa, dist, torch, hi + lo, 2 * qlo, 2 * nq, device)
-                return both
+                return gather_records(psa, dist, torch, hi + lo, 2 * slot0, 2 * total_q, device)
             return hi + lo
         step_minmax()
-        if dist:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            mm = step_minmax()
-        torch.cuda.synchronize(device)
-        if dist:
-            dist.barrier()
-        mm_elapsed = time.perf_counter() - t0
-        if dist:
-            t = torch.tensor([mm_elapsed], dtype=torch.float64, device=device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            mm_elapsed = float(t.item())
+        mm_elapsed, mm = timed(step_minmax, args.steps)
         minmax = {"ms_per_step": 1e3 * mm_elapsed / args.steps,
                   "searches_per_s": 2 * (pairs_step // (total * m)) * args.steps / mm_elapsed,
                   "equivalent_pair_scores_per_s": 2 * pairs_step * args.steps / mm_elapsed,
                   "note": "MIN and MAX result of every query per step; the class counts are shared by the two modes, "
                           "bounds / candidates / exact re-score are per mode; 'equivalent' counts the pairs two "
                           "separate searches would score"}
+
+        # SURVEY.md 8(d) region: the same step with the sequences handed over as pageable HOST buffers
+        # (psa_set_seq1 + psa_search_batch: H2D over PCIe inside the timed region).  Never `value`.
+        h1 = s1.tobytes()
+        hq = [queries[q].tobytes() for q in range(qlo, qhi)]
+
+        def step_from_host():
+            ctx.set_seq1(h1)
+            return ctx.search_batch(hq) if hq else []
+        step_from_host()
+        fh_elapsed, fh = timed(step_from_host, max(2, args.steps // 2))
+        from_host = {"ms_per_step": 1e3 * fh_elapsed / max(2, args.steps // 2),
+                     "value": pairs_step * max(2, args.steps // 2) / fh_elapsed, "unit": "char-pair scores/s",
+                     "note": "psa_set_seq1 + psa_search_batch from pageable host memory (1 MB + Q x 10 kB over PCIe "
+                             "per step); `value` above starts from HBM-resident inputs"}
+        from_host_equal = [r.as_tuple() for r in fh] == [r.as_tuple() for r in (results[slot0:slot0 + qhi - qlo] if world > 1 else results)]
 
     # End-to-end latency of ONE blocking search of query 0, again from raw ASCII in HBM
     # (library profiling off: its event records would sit between the kernels).
@@ -277,7 +392,7 @@ def main():
             score = psa.lib.gpu_run_program_layout(C.addressof(data), cap1, cap2, C.byref(mutant), lo1, hi1)
             if k >= 2:
                 legacy.append(time.perf_counter() - t0)
-        assert (mutant.offset, score) == (one.offset, one.score), "gpu_run_program disagrees with psa_search"
+        legacy_equal = (mutant.offset, score) == (one.offset, one.score)
         legacy_ms = 1e3 * sorted(legacy)[len(legacy) // 2]
     # Kernels: HIP events recorded by the library on the stream it launches the kernel on.
     # (1) the count kernel of a single search; (2) the dominant kernel of the timed region: in batch mode one
@@ -306,30 +421,51 @@ def main():
             pass            # the sequential engine's batches are not timed per launch: keep the single-search kernel
     ctx.set_profiling(False)
     pairs_launch = (hi1 - lo1) * m * kernel_queries
-    achieved = BYTES_PER_PAIR * pairs_launch / kernel_s / 1e9
+    algorithmic_gbs = BYTES_PER_PAIR * pairs_launch / kernel_s / 1e9
+
+    # self-check (rank 0's query 0 is BASELINE.json configs[2]): committed oracle goldens, batch == single search
+    verified = None
+    if rank == 0 and args.mode == "batch" and (n, m) == (1_000_000, 10_000) and qlo == 0:
+        g_max, g_min = golden_case("c3_max"), golden_case("c3_min")
+        mine_max = results[0]
+        nmine = qhi - qlo
+        mine_min = mm[(2 * slot0 if world > 1 else 0) + nmine] if mm else None
+        singles = 0
+        for q in range(0, nmine, max(1, nmine // 8)):                       # a few queries against single searches
+            ctx.set_seq2_device(tq[q].data_ptr(), m)
+            r = ctx.search(0, total)
+            b = results[(slot0 if world > 1 else 0) + q]
+            if (r.score, r.offset, r.char_offset, r.ch) != (b.score, b.offset, b.char_offset, b.ch):
+                singles = -10**6
+            singles += 1
+        verified = {"query0_max_equals_golden": bool(g_max and matches_golden(mine_max, g_max)),
+                    "query0_min_equals_golden": bool(g_min and mine_min is not None and matches_golden(mine_min, g_min)),
+                    "batch_equals_single_search_queries": singles,
+                    "batch_from_host_equals_batch": bool(from_host_equal),
+                    "gpu_run_program_equals_psa_search": bool(legacy_equal),
+                    "sequential_engine_fallbacks": ctx.fallback_count(),
+                    "golden": "tests/golden/synthetic_golden.json c3_max / c3_min (CPU oracle, 48 s each)"}
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
         traffic = json.load(open(tpath)).get(kernel_name)
 
-    # The physical bound of the count kernels is VALU issue: wave-instructions per launch from the committed PMC
-    # profile (SQ_INSTS_VALU) over the live kernel time, against 1024 SIMDs x 1 wave64 instruction per 2 cycles at
-    # 2.4 GHz (the full-rate ops; the loop's v_alignbit_b32 issue at half of that).
+    # The bound of the count kernels is VALU issue (bit-sliced counting out of LDS; HBM sees a few MB per launch):
+    # wave-instructions per launch from the committed PMC profile (SQ_INSTS_VALU) over the live kernel time, against
+    # 1024 SIMDs x 1 wave64 instruction per 2 cycles at 2.4 GHz.
     valu = None
-    cpath = os.path.join(ROOT, "profiles", "r01_filter_counters.csv")
-    if os.path.exists(cpath):
+    cpath = latest_profile("r*_counters.csv")
+    if cpath:
         import csv
         for row in csv.DictReader(open(cpath)):
             if row["counter"] == "SQ_INSTS_VALU" and kernel_name.split("<")[0] in row["kernel"] and \
-                    (("<" not in kernel_name) or kernel_name in row["kernel"]):
+                    (("<" not in kernel_name) or kernel_name in row["kernel"]) and "seq" not in os.path.basename(cpath):
                 insts = float(row["mean_per_dispatch"])
                 if "duo" in kernel_name:
                     insts *= kernel_queries / 32.0          # the profile's launches served 32 queries each
-                peak = 1024 * 2.4e9 / 2
-                valu = {"wave_instructions_per_launch": insts, "achieved_per_s": insts / kernel_s, "peak_per_s": peak,
-                        "frac": insts / kernel_s / peak,
-                        "note": "peak = 1024 SIMDs x 2.4 GHz / 2 cycles per full-rate wave64 instruction"}
+                valu = {"wave_instructions_per_launch": insts, "achieved_per_s": insts / kernel_s,
+                        "source": os.path.relpath(cpath, ROOT)}
                 break
 
     # Calibration of the achievable HBM bandwidth on this GPU: device-to-device copy of 1 GiB,
@@ -349,55 +485,78 @@ def main():
         del src, dst
 
     q0 = results[0] if (args.mode == "shard" or world > 1 or qlo == 0) else one
+    if valu:
+        roofline = {"bound": "valu", "achieved": valu["achieved_per_s"] / 1e9, "peak": VALU_PEAK / 1e9,
+                    "unit": "G wave64-instructions/s", "frac": valu["achieved_per_s"] / VALU_PEAK}
+    else:       # no committed PMC profile of this kernel: only the algorithmic-bytes model is available
+        roofline = {"bound": "hbm", "achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": algorithmic_gbs / HBM_PEAK_GBS}
+    roofline.update({
+        "traffic": traffic, "kernel": kernel_name, "kernel_ms": 1e3 * kernel_s, "queries_per_launch": kernel_queries,
+        "valu": dict(valu, peak_per_s=VALU_PEAK, note="peak = 1024 SIMDs x 2.4 GHz / 2 cycles per full-rate wave64 "
+                     "instruction; instructions per launch from the committed rocprofv3 PMC pass") if valu else None,
+        "hbm_algorithmic": {"achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "ratio_to_peak": algorithmic_gbs / HBM_PEAK_GBS,
+                            "bytes_per_launch": BYTES_PER_PAIR * pairs_launch,
+                            "note": "SURVEY.md 8(d) model, 2 B per char pair: NOT binding — tiles are reused from LDS, "
+                                    "the kernel's physical HBM traffic is `traffic` bytes per launch"},
+        "single_search_kernel": {"kernel": single_kernel_name, "kernel_ms": 1e3 * single_kernel_s,
+                                 "hbm_algorithmic_GBps": BYTES_PER_PAIR * (hi1 - lo1) * m / single_kernel_s / 1e9},
+        "measured_hbm_GBps": (traffic / kernel_s / 1e9) if traffic else None,
+        "hbm_copy_calibration_GBps": copy_gbs})
     line = {
         "metric": "char-pair scores/sec (whole job), |Seq1|=1M |Seq2|=10k MAX searches",
         "value": value, "unit": "char-pair scores/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": (f"batch of {nq} independent searches per step: {nq} Seq2 queries (|Seq2|={m}, seeds "
+            "workload": (f"batch of {nq} independent searches per step and GPU: Seq2 queries (|Seq2|={m}, seeds "
                          f"{SEED_QUERY0}..) vs one |Seq1|={n} (seed {SEED_SEQ1}), MAX, weights 1.5 2.6 0.3 0.2; "
-                         f"query 0 = BASELINE.json configs[2]; queries dealt to {world} GPU(s) (configs[4] sharding)"
+                         f"query 0 = BASELINE.json configs[2]; "
+                         + (f"{world} GPU(s) x {nq} queries (BASELINE.json configs[4] batch per GPU)" if weak or world == 1
+                            else f"{nq} queries dealt to {world} GPU(s) (BASELINE.json configs[4])")
                          if args.mode == "batch" else
                          f"one search |Seq1|={n} |Seq2|={m} MAX (BASELINE.json configs[2]/[3]), offsets sharded "
                          f"over {world} GPU(s)"),
-            "offsets_per_query": total, "queries_per_step": nq, "pairs_per_step": pairs_step,
+            "offsets_per_query": total, "queries_per_step": (total_q if args.mode == "batch" else 1),
+            "pairs_per_step": pairs_step,
             "parallelism": (f"query-shard x{world}" if args.mode == "batch" else f"offset-shard x{world}"),
             "exchange": "none" if world == 1 else "1 RCCL all-reduce(sum) of one-hot int64 records per step",
-            "timed_region": "raw ASCII in HBM -> encode + Seq1 class planes -> search -> records on host"},
+            "timed_region": "raw ASCII in HBM -> encode -> search -> records on host"},
         "result_query0": {"offset": q0.offset, "char_offset": q0.char_offset,
                           "ch": chr(q0.ch) if q0.ch else "", "score": q0.score},
+        "verified": verified,
         "single_search_latency_ms": 1e3 * sorted(lat)[len(lat) // 2],
         "single_search_latency_from_host_buffers_ms": 1e3 * sorted(host_lat)[len(host_lat) // 2],
         "gpu_run_program_latency_ms": legacy_ms,
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": kernel_name, "kernel_ms": 1e3 * kernel_s, "queries_per_launch": kernel_queries,
-                     "single_search_kernel": {"kernel": single_kernel_name, "kernel_ms": 1e3 * single_kernel_s,
-                                              "achieved": BYTES_PER_PAIR * (hi1 - lo1) * m / single_kernel_s / 1e9},
-                     "measured_hbm_GBps": (traffic / kernel_s / 1e9) if traffic else None,
-                     "hbm_copy_calibration_GBps": copy_gbs,
-                     "valu": valu,
-                     "algorithmic_bytes_per_launch": BYTES_PER_PAIR * pairs_launch,
-                     "note": "algorithmic bytes = 2 B per char pair (SURVEY.md 8d); tiles are reused from "
-                             "LDS/L2 so physical HBM traffic is a few MB per search (frac > 1 is expected: "
-                             "the physical bound of this kernel is VALU issue, see DESIGN.md)"},
+        "roofline": roofline,
     }
     if minmax:
         line["minmax_batch"] = minmax
+    if from_host:
+        line["batch_from_host"] = from_host
     if emulated:
         line["config"]["emulated_world"] = args.emulate_world
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(s1.tobytes(), queries[0].tobytes(), total, m)
         # the reference's own thread count (THREADS_COUNT, def.h:18)
         line["cpu_baseline_4_threads"] = cpu_baseline(s1.tobytes(), queries[0].tobytes(), total, m, budget_s=4.0, threads=4)
+    failed = False
+    if verified is not None:
+        failed = not (verified["query0_max_equals_golden"] and verified["query0_min_equals_golden"] and
+                      verified["batch_equals_single_search_queries"] > 0 and verified["batch_from_host_equals_batch"] and
+                      verified["gpu_run_program_equals_psa_search"])
     if rank == 0:
         print(json.dumps(line), flush=True)
+        if failed:
+            print("bench.py: SELF-CHECK FAILED (see \"verified\")", file=sys.stderr)
     ctx.close()
     if dist:
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit(1)
 
 
 if __name__ == "__main__":

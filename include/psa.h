@@ -64,17 +64,36 @@ typedef struct psa_context psa_context;
  * (min) with {-1,-1,'\0'} when nothing is found (cuda_funcs.cu:143-145,
  * 158-161).  Never writes cpu_data, retains no pointer.  On a device error:
  * message on stderr + exit(EXIT_FAILURE), like the reference.
- * ProgramData must have been compiled with this library's PSA_SEQ*_MAX_LEN.
+ *
+ * Layout.  A plain symbol cannot see how its caller compiled ProgramData, so the
+ * library's gpu_run_program reads the reference's STOCK struct (def.h:35-36:
+ * seq1[10001], seq2[5001], 15,048 bytes): an unmodified reference build that links
+ * this library and calls gpu_run_program by name is served correctly.  A caller
+ * compiled with other limits (this repo's own program uses 1,000,001 / 10,001)
+ * must go through gpu_run_program_layout; including this header does that
+ * automatically (the inline below), so `gpu_run_program(&data, ...)` is right for
+ * whatever PSA_SEQ*_MAX_LEN the including translation unit was built with.
  * ------------------------------------------------------------------------- */
-double gpu_run_program(const ProgramData* cpu_data, Mutant* returned_mutant,
-                       int first_offset, int last_offset);
 
-/* Same, for a caller whose ProgramData was compiled with other array limits
- * (e.g. the reference's stock 10001/5001): seq1_cap/seq2_cap are that
- * caller's SEQ1_MAX_LEN / SEQ2_MAX_LEN; field offsets are derived from them
- * (is_max@0, weights@8, seq1@40, seq2@40+seq1_cap). */
+/* For a caller whose ProgramData was compiled with array limits seq1_cap /
+ * seq2_cap (its SEQ1_MAX_LEN / SEQ2_MAX_LEN); field offsets are derived from
+ * them (is_max@0, weights@8, seq1@40, seq2@40+seq1_cap). */
 double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2_cap,
                               Mutant* returned_mutant, int first_offset, int last_offset);
+
+#if defined(PSA_BUILDING_LIBRARY) || \
+    (PSA_SEQ1_MAX_LEN == PSA_REF_SEQ1_MAX_LEN && PSA_SEQ2_MAX_LEN == PSA_REF_SEQ2_MAX_LEN)
+/* the exported symbol: stock reference layout */
+double gpu_run_program(const ProgramData* cpu_data, Mutant* returned_mutant,
+                       int first_offset, int last_offset);
+#else
+static inline double gpu_run_program(const ProgramData* cpu_data, Mutant* returned_mutant,
+                                     int first_offset, int last_offset)
+{
+    return gpu_run_program_layout(cpu_data, PSA_SEQ1_MAX_LEN, PSA_SEQ2_MAX_LEN, returned_mutant,
+                                  first_offset, last_offset);
+}
+#endif
 
 /* ---------------------------------------------------------------------------
  * Persistent context: owns the device buffers the reference allocates and

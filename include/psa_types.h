@@ -16,6 +16,10 @@
  *                    the default is the BASELINE.json size (1M / 10k); build
  *                    with -DPSA_SEQ1_MAX_LEN=10001 -DPSA_SEQ2_MAX_LEN=5001 to
  *                    get the reference's exact 15,048-byte ProgramData.
+ *                    The library SYMBOL gpu_run_program always reads the
+ *                    reference's stock layout (PSA_REF_SEQ*_MAX_LEN); psa.h
+ *                    routes callers built with other limits through
+ *                    gpu_run_program_layout.
  */
 #ifndef PSA_TYPES_H
 #define PSA_TYPES_H
@@ -23,6 +27,10 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+
+/* the reference's stock limits (def.h:35-36): sizeof(ProgramData) == 15,048 with these */
+#define PSA_REF_SEQ1_MAX_LEN (10000 + 1)
+#define PSA_REF_SEQ2_MAX_LEN (5000 + 1)
 
 #ifndef PSA_SEQ1_MAX_LEN
 #define PSA_SEQ1_MAX_LEN (1000000 + 1)

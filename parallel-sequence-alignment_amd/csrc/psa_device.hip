@@ -150,9 +150,12 @@ __global__ __launch_bounds__(kBlock) void psa_seq_kernel(SeqArgs a)
 
     // Window of Seq1 codes for chars i0..i0+3 of all R offsets: bytes
     // o0+i0 .. o0+i0+R+2, held in (d0, d1).
-    unsigned int d0 = *reinterpret_cast<const unsigned int*>(p);
+    // (p is only byte-aligned for R = 1, 2: memcpy keeps the 4-byte loads well-defined; one global_load_dword each)
+    unsigned int d0;
+    __builtin_memcpy(&d0, p, 4);
     for (int i0 = 0; i0 < a.m4; i0 += 4) {
-        const unsigned int d1 = *reinterpret_cast<const unsigned int*>(p + i0 + 4);
+        unsigned int d1;
+        __builtin_memcpy(&d1, p + i0 + 4, 4);
         const uint4 rows = *reinterpret_cast<const uint4*>(a.s2rows + i0);   // wave-uniform -> scalar load
         const unsigned long long win = ((unsigned long long)d1 << 32) | d0;
         const unsigned int row[4] = {rows.x >> kRowShift, rows.y >> kRowShift, rows.z >> kRowShift, rows.w >> kRowShift};
@@ -1847,9 +1850,12 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
     return r.score;
 }
 
+// The exported legacy symbol reads the reference's STOCK ProgramData (def.h:35-36: 10001 / 5001, 15,048 bytes):
+// that is what an unmodified reference build passes.  Callers built with other limits use
+// gpu_run_program_layout (psa.h does it for them).
 double gpu_run_program(const ProgramData* cpu_data, Mutant* returned_mutant, int first_offset, int last_offset)
 {
-    return gpu_run_program_layout(cpu_data, PSA_SEQ1_MAX_LEN, PSA_SEQ2_MAX_LEN, returned_mutant,
+    return gpu_run_program_layout(cpu_data, PSA_REF_SEQ1_MAX_LEN, PSA_REF_SEQ2_MAX_LEN, returned_mutant,
                                   first_offset, last_offset);
 }
 

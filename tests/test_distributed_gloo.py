@@ -98,3 +98,45 @@ def test_query_sharded_batch_gather(oracle, psa, world, nq):
         assert out[rank] == want
     blocks = [__import__("bench").query_block(nq, world, r) for r in range(world)]
     assert blocks[0][0] == 0 and blocks[-1][1] == nq and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+
+
+def _run_bench(args, env_extra=None, timeout=240):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, env=env, capture_output=True,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_gpus_n_launches_n_ranks(psa, scaling):
+    """`python bench.py --gpus 2` (no launcher around it) starts 2 ranks itself and reports n_gpus == 2
+    (VERDICT r1 missing #2).  Device-free rehearsal: gloo, stubbed search, the real record exchange."""
+    rc, line, err = _run_bench(["--gpus", "2", "--stub-search", "--queries", "5", "--scaling", scaling])
+    assert rc == 0, err[-2000:]
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling
+    assert line["verified"]["exchange"] is True
+    assert line["config"]["records"] == (10 if scaling == "weak" else 5)
+
+
+def test_bench_refuses_world_size_mismatch(psa):
+    """Under a launcher with another world size the bench exits non-zero instead of misreporting n_gpus."""
+    rc, line, err = _run_bench(["--gpus", "2", "--stub-search"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and line is None
+    rc, line, err = _run_bench(["--gpus", "1", "--stub-search"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and line is None
+
+
+def test_bench_refuses_more_gpus_than_devices(psa):
+    """--gpus 8 on a box with fewer devices: non-zero exit before anything is launched (here: 0 devices)."""
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("this box has 8 devices")
+    rc, line, err = _run_bench(["--gpus", "8", "--steps", "1"])
+    assert rc != 0 and line is None and "HIP device" in err

@@ -198,6 +198,21 @@ def test_legacy_gpu_run_program(psa, oracle, reference_records):
     buf[10041:10041 + len(s2)] = s2
     data = (C.c_char * len(buf)).from_buffer(buf)
     m = psa.Mutant()
+    # the exported symbol itself, exactly as a stock reference build would call it (cpu_funcs.c:180): a
+    # 15,048-byte struct and nothing else (a canary behind the struct would trip on any over-read at 1M limits)
+    score = psa.lib.gpu_run_program(C.addressof(data), C.byref(m), 0, len(s1) - len(s2) + 1)
+    assert (m.offset, m.char_offset, m.ch, score) == (4505, 144, b"E", -4879.0)
+    # seq1 filling its array to the last byte before the NUL (n = 10000), seq2 likewise (m = 5000): record 9
+    w9, s19, s29, max9 = reference_records[9]
+    assert (len(s19), len(s29)) == (10000, 5000)
+    full = bytearray(15048)
+    full[0:4] = int(max9).to_bytes(4, "little")
+    full[8:40] = np.array(w9, np.float64).tobytes()
+    full[40:40 + 10000] = s19
+    full[10041:10041 + 5000] = s29
+    fdata = (C.c_char * len(full)).from_buffer(full)
+    score = psa.lib.gpu_run_program(C.addressof(fdata), C.byref(m), 0, 5001)
+    assert (score, m.offset, m.char_offset, m.ch.decode()) == oracle.search(s19, s29, w9, max9, threads=4)
     score = psa.lib.gpu_run_program_layout(C.addressof(data), 10001, 5001, C.byref(m), 0, len(s1) - len(s2) + 1)
     assert (m.offset, m.char_offset, m.ch, score) == (4505, 144, b"E", -4879.0)
     # a sub-range, as divide_execute_tasks hands it over (cpu_funcs.c:144-146,180)
@@ -615,6 +630,53 @@ def test_batch_minmax_full_size(psa):
         hi2, lo2 = c.search_batch_minmax_device(tq.data_ptr(), nq, m, m)      # from a MIN context
         assert [key(r) for r in hi] == [key(r) for r in want_hi] == [key(r) for r in hi2]
         assert [key(r) for r in lo] == [key(r) for r in want_lo] == [key(r) for r in lo2]
+        assert c.fallback_count() == 0
+        gold = {c_["name"]: c_ for c_ in json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))["cases"]}
+        for res, name in ((hi[0], "c3_max"), (lo[0], "c3_min")):
+            g = gold[name]
+            assert (res.offset, res.char_offset, chr(res.ch), "%.17g" % res.score) == (g["offset"], g["char_offset"], g["ch"], g["score"])
+
+
+def test_configs4_256_queries_minmax_every_winner_verified(psa, oracle):
+    """BASELINE.json configs[4] at its stated size: 256 queries x (1M x 10k), MIN + MAX from one pass
+    (psa_search_batch_minmax_device, ~25 ms of GPU).  EVERY one of the 512 winners is re-derived on the oracle at
+    its offset (find_best_mutant_offset, cpu_funcs.c:257-300: score bits, char_offset, ch); sampled offsets of every
+    query must not beat its winner in the is_swapable order (cuda_funcs.cu:290-307); 16 queries are compared with
+    single searches; query 0 with the committed goldens (48 s of CPU oracle each); no search may leave the filter
+    engine."""
+    import torch
+    n, m, nq = 1_000_000, 10_000, 256
+    s1 = psa.generate_sequence_np(1002, n)
+    qs = np.stack([psa.generate_sequence_np(2002 + q, m) for q in range(nq)])
+    t1 = torch.from_numpy(s1).cuda()
+    tq = torch.from_numpy(qs).cuda()
+    total = n - m + 1
+    with psa.Context(0) as c:
+        c.set_weights(W_README, True)
+        c.set_seq1_device(t1.data_ptr(), n)
+        hi, lo = c.search_batch_minmax_device(tq.data_ptr(), nq, m, m)
+        assert c.fallback_count() == 0
+        s1b = s1.tobytes()
+        rng = np.random.default_rng(7)
+        for q in range(nq):
+            s2b = qs[q].tobytes()
+            for res, is_max in ((hi[q], True), (lo[q], False)):
+                assert 0 <= res.offset < total and res.shard == q and res.pairs == total * m
+                score, ci, ch = oracle.score_offset(s1b, s2b, W_README, is_max, res.offset)
+                assert (res.score, res.char_offset, chr(res.ch)) == (score, ci, ch), (q, is_max)
+                # dominance over a sample of other offsets (neighbours of the winner included)
+                sample = list(rng.integers(0, total, 6)) + [max(res.offset - 1, 0), min(res.offset + 1, total - 1)]
+                for o in sample:
+                    so, _, _ = oracle.score_offset(s1b, s2b, W_README, is_max, int(o))
+                    better = so > res.score if is_max else so < res.score
+                    assert not better and not (so == res.score and o < res.offset), (q, is_max, int(o))
+        # single searches of 16 of the queries, both modes
+        key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+        for q in range(0, nq, 16):
+            for res, is_max in ((hi[q], True), (lo[q], False)):
+                c.set_weights(W_README, is_max)
+                c.set_seq2_device(tq[q].data_ptr(), m)
+                assert key(c.search()) == key(res), (q, is_max)
         assert c.fallback_count() == 0
         gold = {c_["name"]: c_ for c_ in json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))["cases"]}
         for res, name in ((hi[0], "c3_max"), (lo[0], "c3_min")):
