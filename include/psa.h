@@ -172,6 +172,27 @@ int psa_duo_retry_count(psa_context* ctx);
  * up to 2048 arbitrary offsets, without the filter in front of it. */
 psa_status psa_debug_rescore(psa_context* ctx, const int32_t* offsets, int count, double* scores);
 
+/* ---------------------------------------------------------------------------
+ * Device group: ONE search sharded over several GPUs of this node — the reference's
+ * MPI layer (ranks, MPI_Bcast of ProgramData, MPI_Allreduce(MAXLOC|MINLOC) +
+ * MPI_Send/Recv of the Mutant: cpu_funcs.c:49-94, split rule cpu_funcs.c:128-133)
+ * as one process: one context per device, psa_shard_range split, all shards searched
+ * concurrently, ONE RCCL all-gather of the 32-byte psa_result records over xGMI,
+ * psa_fold.  librccl is loaded when the first group is created.  The legacy entry
+ * points use a group when PSA_DEVICES=0,1,... lists more than one device.
+ * ------------------------------------------------------------------------- */
+typedef struct psa_group psa_group;
+psa_status psa_group_create(const int* devices, int ndev, psa_group** out);
+void       psa_group_destroy(psa_group* g);
+int        psa_group_size(const psa_group* g);
+psa_status psa_group_set_weights(psa_group* g, const double weights[4], int is_max);
+psa_status psa_group_set_seq1(psa_group* g, const char* seq1, int n);   /* every device gets Seq1 (MPI_Bcast) */
+psa_status psa_group_set_seq2(psa_group* g, const char* seq2, int m);
+/* Offsets [first_offset,last_offset) over the group.  shard_records (optional, [ndev]) receives the
+ * exchanged per-device records (shard = index in the group; offset -1 for an empty shard). */
+psa_status psa_search_sharded(psa_group* g, int first_offset, int last_offset, psa_result* out,
+                              psa_result* shard_records);
+
 /* Fold of per-shard records with the reference's merge order
  * (is_swapable, cuda_funcs.cu:290-307: strictly better score, then lower
  * offset, then lower char_offset).  Host-only, no device needed. */

@@ -10,6 +10,9 @@
 // the kernel tracks only the best delta *rank* per offset (integer max), the
 // substituted position/character is recovered for the winner alone.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>      // types and prototypes only: librccl is loaded at run time, by psa_group_create
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -1795,11 +1798,237 @@ int psa_reselect_count(psa_context* c) { return c ? c->reselects : 0; }
 // barriers timed out (never expected; the debug library can force it: PSA_DUO_FORCE_TIMEOUT).
 int psa_duo_retry_count(psa_context* c) { return c ? c->duo_retries : 0; }
 
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// device group: one search sharded over several GPUs of the node
+// (the reference's MPI split and merge, cpu_funcs.c:49-94 and 128-133, in one process)
+// ---------------------------------------------------------------------------
+namespace {
+
+// RCCL entry points, resolved from librccl.so.1 when the first group is created: the single-GPU
+// product path neither needs nor loads RCCL.
+struct RcclApi {
+    void* handle = nullptr;
+    decltype(&ncclCommInitAll)  comm_init_all = nullptr;
+    decltype(&ncclCommDestroy)  comm_destroy = nullptr;
+    decltype(&ncclAllGather)    all_gather = nullptr;
+    decltype(&ncclGroupStart)   group_start = nullptr;
+    decltype(&ncclGroupEnd)     group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rccl_mutex;
+
+bool load_rccl(std::string* err)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return true;
+    void* h = nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        if (h) break;
+    }
+    if (!h) { *err = std::string("cannot load librccl: ") + dlerror(); return false; }
+    RcclApi api;
+    api.handle = h;
+    api.comm_init_all = reinterpret_cast<decltype(api.comm_init_all)>(dlsym(h, "ncclCommInitAll"));
+    api.comm_destroy = reinterpret_cast<decltype(api.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    api.all_gather = reinterpret_cast<decltype(api.all_gather)>(dlsym(h, "ncclAllGather"));
+    api.group_start = reinterpret_cast<decltype(api.group_start)>(dlsym(h, "ncclGroupStart"));
+    api.group_end = reinterpret_cast<decltype(api.group_end)>(dlsym(h, "ncclGroupEnd"));
+    api.error_string = reinterpret_cast<decltype(api.error_string)>(dlsym(h, "ncclGetErrorString"));
+    if (!api.comm_init_all || !api.comm_destroy || !api.all_gather || !api.group_start || !api.group_end || !api.error_string) {
+        *err = "librccl lacks an expected entry point";
+        dlclose(h);
+        return false;
+    }
+    g_rccl = api;
+    return true;
+}
+
+#define PSA_NCCL(call)                                                                         \
+    do {                                                                                       \
+        ncclResult_t r_ = (call);                                                              \
+        if (r_ != ncclSuccess) {                                                               \
+            set_last_error(std::string(#call) + ": " + g_rccl.error_string(r_));               \
+            return PSA_ERR_DEVICE;                                                             \
+        }                                                                                      \
+    } while (0)
+
+}  // namespace
+
+struct psa_group {
+    std::vector<int>          devices;
+    std::vector<psa_context*> ctx;
+    std::vector<ncclComm_t>   comm;
+    std::vector<psa_result*>  d_send;     // per device: its 32-byte record
+    std::vector<psa_result*>  d_recv;     // per device: all ndev records after the exchange
+    psa_result*               h_send = nullptr;   // pinned [ndev]
+    psa_result*               h_recv = nullptr;   // pinned [ndev][ndev]
+    int is_max = 1;
+    bool have_weights = false;
+    int n = -1, m = -1;
+};
+
+extern "C" {
+
+psa_status psa_group_create(const int* devices, int ndev, psa_group** out)
+{
+    if (!out || !devices || ndev < 1) { set_last_error("psa_group_create: bad arguments"); return PSA_ERR_ARG; }
+    *out = nullptr;
+    for (int i = 0; i < ndev; ++i)
+        for (int k = 0; k < i; ++k)
+            if (devices[i] == devices[k]) { set_last_error("psa_group_create: a device is listed twice"); return PSA_ERR_ARG; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1) { set_last_error("no HIP device available"); return PSA_ERR_DEVICE; }
+    std::string err;
+    if (!load_rccl(&err)) { set_last_error(err); return PSA_ERR_DEVICE; }
+    psa_group* g = new psa_group();
+    g->devices.assign(devices, devices + ndev);
+    psa_status st = [&]() -> psa_status {
+        for (int i = 0; i < ndev; ++i) {
+            psa_context* c = nullptr;
+            PSA_TRY(psa_create(devices[i], nullptr, &c));
+            g->ctx.push_back(c);
+        }
+        g->comm.assign((size_t)ndev, nullptr);
+        PSA_NCCL(g_rccl.comm_init_all(g->comm.data(), ndev, devices));          // one communicator over the listed GPUs (xGMI)
+        g->d_send.assign((size_t)ndev, nullptr);
+        g->d_recv.assign((size_t)ndev, nullptr);
+        for (int i = 0; i < ndev; ++i) {
+            PSA_HIP(hipSetDevice(devices[i]));
+            PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_send[i]), sizeof(psa_result)));
+            PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_recv[i]), sizeof(psa_result) * (size_t)ndev));
+        }
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_send), sizeof(psa_result) * (size_t)ndev, hipHostMallocDefault));
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_recv), sizeof(psa_result) * (size_t)ndev * ndev, hipHostMallocDefault));
+        return PSA_OK;
+    }();
+    if (st != PSA_OK) { psa_group_destroy(g); return st; }
+    *out = g;
+    return PSA_OK;
+}
+
+void psa_group_destroy(psa_group* g)
+{
+    if (!g) return;
+    for (size_t i = 0; i < g->comm.size(); ++i)
+        if (g->comm[i]) (void)g_rccl.comm_destroy(g->comm[i]);
+    for (size_t i = 0; i < g->d_send.size(); ++i) {
+        (void)hipSetDevice(g->devices[i]);
+        (void)hipFree(g->d_send[i]);
+        (void)hipFree(g->d_recv[i]);
+    }
+    if (g->h_send) (void)hipHostFree(g->h_send);
+    if (g->h_recv) (void)hipHostFree(g->h_recv);
+    for (psa_context* c : g->ctx) psa_destroy(c);
+    delete g;
+}
+
+int psa_group_size(const psa_group* g) { return g ? (int)g->ctx.size() : 0; }
+
+psa_status psa_group_set_weights(psa_group* g, const double weights[4], int is_max)
+{
+    if (!g) { set_last_error("group is NULL"); return PSA_ERR_ARG; }
+    for (psa_context* c : g->ctx) PSA_TRY(psa_set_weights(c, weights, is_max));
+    g->is_max = is_max ? 1 : 0;
+    g->have_weights = true;
+    return PSA_OK;
+}
+
+// Every device receives the whole sequences (the reference broadcasts ProgramData to every rank,
+// cpu_funcs.c:49-52; a shard only reads its offsets' window).  Copies and encodes are enqueued on all
+// devices first and synchronised afterwards, so the uploads of the devices overlap.
+static psa_status group_set_seq(psa_group* g, const char* seq, int len, bool first_seq)
+{
+    if (!g || !seq || len < 1) { set_last_error("psa_group_set_seq: bad arguments"); return PSA_ERR_ARG; }
+    for (psa_context* c : g->ctx) {
+        PSA_TRY(ensure_device(c));
+        PSA_TRY(stage_host(c, seq, (size_t)len));
+        if (first_seq) PSA_TRY(encode_seq1(c, c->d_raw, len));
+        else PSA_TRY(encode_seq2(c, c->slot[0], c->d_raw, len, c->stream));
+    }
+    for (psa_context* c : g->ctx) {
+        PSA_TRY(ensure_device(c));
+        PSA_TRY(check_bad_now(c));
+        PSA_TRY(report_bad(c));
+    }
+    (first_seq ? g->n : g->m) = len;
+    return PSA_OK;
+}
+
+psa_status psa_group_set_seq1(psa_group* g, const char* seq1, int n) { return group_set_seq(g, seq1, n, true); }
+psa_status psa_group_set_seq2(psa_group* g, const char* seq2, int m) { return group_set_seq(g, seq2, m, false); }
+
+// Offsets [first,last) split over the group's devices with the reference's rank rule (psa_shard_range,
+// cpu_funcs.c:128-133), all shards searched concurrently, ONE RCCL all-gather of the 32-byte records
+// (in place of MPI_Allreduce(MAXLOC|MINLOC) + MPI_Send/Recv of the Mutant, cpu_funcs.c:71-94), then the
+// is_swapable fold (ties: lowest offset = lowest shard, like MPI_MAXLOC's lowest rank).
+psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out, psa_result* shard_records)
+{
+    if (!g || !out) { set_last_error("psa_search_sharded: NULL argument"); return PSA_ERR_ARG; }
+    if (!g->have_weights || g->n < 0 || g->m < 0) {
+        set_last_error("weights, seq1 and seq2 must be set before a search");
+        return PSA_ERR_STATE;
+    }
+    const int ndev = (int)g->ctx.size();
+    PSA_TRY(check_ready(g->ctx[0], g->m, first, last));
+    const int total = last - first;
+    std::vector<int> lo((size_t)ndev), hi((size_t)ndev);
+    for (int i = 0; i < ndev; ++i) {
+        psa_shard_range(total, ndev, i, &lo[i], &hi[i]);
+        lo[i] += first;
+        hi[i] += first;
+        if (hi[i] > lo[i]) PSA_TRY(psa_search_async(g->ctx[i], lo[i], hi[i]));
+    }
+    for (int i = 0; i < ndev; ++i) {
+        psa_result r;
+        r.score = g->is_max ? -INFINITY : INFINITY;          // an empty shard: "nothing found" (cuda_funcs.cu:158-161)
+        r.offset = -1; r.char_offset = -1; r.ch = 0; r.pairs = 0;
+        if (hi[i] > lo[i]) PSA_TRY(psa_search_wait(g->ctx[i], &r));
+        r.shard = i;
+        g->h_send[i] = r;
+    }
+    // the exchange: every device contributes its record, every device ends up with all of them
+    for (int i = 0; i < ndev; ++i) {
+        PSA_HIP(hipSetDevice(g->devices[i]));
+        PSA_HIP(hipMemcpyAsync(g->d_send[i], &g->h_send[i], sizeof(psa_result), hipMemcpyHostToDevice, g->ctx[i]->stream));
+    }
+    PSA_NCCL(g_rccl.group_start());
+    for (int i = 0; i < ndev; ++i)
+        PSA_NCCL(g_rccl.all_gather(g->d_send[i], g->d_recv[i], sizeof(psa_result), ncclChar, g->comm[i], g->ctx[i]->stream));
+    PSA_NCCL(g_rccl.group_end());
+    for (int i = 0; i < ndev; ++i) {
+        PSA_HIP(hipSetDevice(g->devices[i]));
+        PSA_HIP(hipMemcpyAsync(g->h_recv + (size_t)i * ndev, g->d_recv[i], sizeof(psa_result) * (size_t)ndev,
+                               hipMemcpyDeviceToHost, g->ctx[i]->stream));
+    }
+    for (int i = 0; i < ndev; ++i) {
+        PSA_HIP(hipSetDevice(g->devices[i]));
+        PSA_HIP(hipStreamSynchronize(g->ctx[i]->stream));
+    }
+    // every "rank" folds the same records (checked: the gathered sets are identical)
+    for (int i = 1; i < ndev; ++i)
+        if (std::memcmp(g->h_recv, g->h_recv + (size_t)i * ndev, sizeof(psa_result) * (size_t)ndev) != 0) {
+            set_last_error("internal: the devices disagree about the exchanged records");
+            return PSA_ERR_DEVICE;
+        }
+    if (shard_records) std::memcpy(shard_records, g->h_recv, sizeof(psa_result) * (size_t)ndev);
+    return psa_fold(g->h_recv, ndev, g->is_max, out);
+}
+
+}  // extern "C"
+
+extern "C" {
+
 // ---------------------------------------------------------------------------
 // legacy drop-in (cuda_funcs.h:33)
 // ---------------------------------------------------------------------------
 static std::mutex g_legacy_mutex;
 static psa_context* g_legacy_ctx = nullptr;
+static psa_group*   g_legacy_group = nullptr;
 
 static void legacy_die(const char* what)
 {
@@ -1828,21 +2057,46 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
     const double none = is_max ? -INFINITY : INFINITY;
     if (m < 1 || last_offset <= first_offset) return none;
 
-    if (!g_legacy_ctx) {
-        int device = 0;
-        if (const char* d = std::getenv("PSA_DEVICE")) device = std::atoi(d);
-        if (psa_create(device, nullptr, &g_legacy_ctx) != PSA_OK) legacy_die("Failed to initialise the device context");
+    // PSA_DEVICES=0,1,...: the offsets are sharded over those GPUs (psa_search_sharded: the reference's MPI
+    // ranks, cpu_funcs.c:49-94, as one process and one RCCL exchange); otherwise one GPU, PSA_DEVICE (default 0)
+    std::vector<int> devices;
+    if (const char* list = std::getenv("PSA_DEVICES")) {
+        for (const char* p = list; *p;) {
+            char* end = nullptr;
+            const long v = std::strtol(p, &end, 10);
+            if (end == p) break;
+            devices.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+            if (*end != ',' && *end != '\0') break;
+        }
     }
-    psa_context* c = g_legacy_ctx;
-    if (psa_set_weights(c, weights, is_max) != PSA_OK) legacy_die("Failed to build the score tables");
-    // Both sequences go through the one staging buffer in stream order (copy, encode, copy, encode) and the
-    // call synchronises once, at the end of the search: the alphabet flag comes back with the result tail.
-    if (n < 1 || ensure_device(c) != PSA_OK || stage_host(c, seq1, (size_t)n) != PSA_OK || encode_seq1(c, c->d_raw, n) != PSA_OK)
-        legacy_die("Failed to copy data from host to device (seq1)");
-    if (stage_host(c, seq2, (size_t)m) != PSA_OK || encode_seq2(c, c->slot[0], c->d_raw, m, c->stream) != PSA_OK)
-        legacy_die("Failed to copy data from host to device (seq2)");
     psa_result r;
-    if (psa_search(c, first_offset, last_offset, &r) != PSA_OK) legacy_die("Failed to run the search");
+    if (devices.size() > 1) {
+        if (n < 1) legacy_die("Failed to copy data from host to device (seq1)");
+        if (!g_legacy_group && psa_group_create(devices.data(), (int)devices.size(), &g_legacy_group) != PSA_OK)
+            legacy_die("Failed to initialise the device group (PSA_DEVICES)");
+        psa_group* g = g_legacy_group;
+        if (psa_group_set_weights(g, weights, is_max) != PSA_OK) legacy_die("Failed to build the score tables");
+        if (psa_group_set_seq1(g, seq1, n) != PSA_OK) legacy_die("Failed to copy data from host to device (seq1)");
+        if (psa_group_set_seq2(g, seq2, m) != PSA_OK) legacy_die("Failed to copy data from host to device (seq2)");
+        if (psa_search_sharded(g, first_offset, last_offset, &r, nullptr) != PSA_OK) legacy_die("Failed to run the search");
+    } else {
+        if (!g_legacy_ctx) {
+            int device = devices.size() == 1 ? devices[0] : 0;
+            if (devices.empty())
+                if (const char* d = std::getenv("PSA_DEVICE")) device = std::atoi(d);
+            if (psa_create(device, nullptr, &g_legacy_ctx) != PSA_OK) legacy_die("Failed to initialise the device context");
+        }
+        psa_context* c = g_legacy_ctx;
+        if (psa_set_weights(c, weights, is_max) != PSA_OK) legacy_die("Failed to build the score tables");
+        // Both sequences go through the one staging buffer in stream order (copy, encode, copy, encode) and the
+        // call synchronises once, at the end of the search: the alphabet flag comes back with the result tail.
+        if (n < 1 || ensure_device(c) != PSA_OK || stage_host(c, seq1, (size_t)n) != PSA_OK || encode_seq1(c, c->d_raw, n) != PSA_OK)
+            legacy_die("Failed to copy data from host to device (seq1)");
+        if (stage_host(c, seq2, (size_t)m) != PSA_OK || encode_seq2(c, c->slot[0], c->d_raw, m, c->stream) != PSA_OK)
+            legacy_die("Failed to copy data from host to device (seq2)");
+        if (psa_search(c, first_offset, last_offset, &r) != PSA_OK) legacy_die("Failed to run the search");
+    }
     if (r.offset < 0 || r.ch == 0) return none;   // cuda_funcs.cu:143-144
     returned_mutant->offset = r.offset;
     returned_mutant->char_offset = r.char_offset;

@@ -207,7 +207,18 @@ int main(int argc, char* argv[])
         return 2;
     }
 
-    printf("threads=%2d, processes=%2d\n", 1, 1);
+    /* "processes" = the reference's MPI ranks (cpu_funcs.c:55): here the GPUs the library shards the offsets
+     * over, PSA_DEVICES=0,1,... (one RCCL exchange instead of MPI_Allreduce + Send/Recv, cpu_funcs.c:71-94) */
+    {
+        int devices = 1;
+        const char* list = getenv("PSA_DEVICES");
+        if (list && *list) {
+            const char* p;
+            for (p = list; *p; ++p)
+                if (*p == ',') devices++;
+        }
+        printf("threads=%2d, processes=%2d\n", 1, devices);
+    }
     printf("CUDA percentage set to %d\n", cuda_percentage);
 
     clock_gettime(CLOCK_MONOTONIC, &t0);

@@ -33,6 +33,8 @@ EXPORTED_SYMBOLS = (
     "psa_search_batch", "psa_search_batch_device",
     "psa_search_batch_minmax", "psa_search_batch_minmax_device",
     "psa_debug_counts", "psa_fallback_count", "psa_reselect_count", "psa_duo_retry_count", "psa_debug_rescore",
+    "psa_group_create", "psa_group_destroy", "psa_group_size", "psa_group_set_weights",
+    "psa_group_set_seq1", "psa_group_set_seq2", "psa_search_sharded",
     "psa_fold", "psa_shard_range", "psa_build_tables",
     "psa_set_profiling", "psa_last_timing", "psa_profile_totals", "psa_last_kernel_queries",
     "psa_generate_sequence", "psa_last_error", "psa_version",
@@ -91,6 +93,14 @@ def _load() -> C.CDLL:
     lib.psa_reselect_count.argtypes = [vp]
     lib.psa_duo_retry_count.argtypes = [vp]
     lib.psa_debug_rescore.argtypes = [vp, vp, i, vp]
+    lib.psa_group_create.argtypes = [C.POINTER(i), i, C.POINTER(vp)]
+    lib.psa_group_destroy.argtypes = [vp]
+    lib.psa_group_destroy.restype = None
+    lib.psa_group_size.argtypes = [vp]
+    lib.psa_group_set_weights.argtypes = [vp, dp, i]
+    lib.psa_group_set_seq1.argtypes = [vp, C.c_char_p, i]
+    lib.psa_group_set_seq2.argtypes = [vp, C.c_char_p, i]
+    lib.psa_search_sharded.argtypes = [vp, i, i, C.POINTER(Result), C.POINTER(Result)]
     lib.psa_fold.argtypes = [C.POINTER(Result), i, i, C.POINTER(Result)]
     lib.psa_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.psa_shard_range.restype = None
@@ -336,6 +346,53 @@ class Context:
         a, b, k = C.c_double(), C.c_double(), C.c_int()
         _check(lib.psa_profile_totals(self._h, C.byref(a), C.byref(b), C.byref(k)))
         return a.value, b.value, k.value
+
+
+class Group:
+    """Device group (psa_group_create .. psa_group_destroy): one search sharded over several GPUs of the node,
+    per-device records exchanged by one RCCL all-gather (the reference's MPI layer, cpu_funcs.c:49-94)."""
+
+    def __init__(self, devices: Sequence[int]):
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        _check(lib.psa_group_create(arr, len(devices), C.byref(self._h)))
+        self.n = self.m = None
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value and lib is not None:
+            lib.psa_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def size(self) -> int:
+        return lib.psa_group_size(self._h)
+
+    def set_weights(self, weights: Sequence[float], is_max: bool):
+        _check(lib.psa_group_set_weights(self._h, _weights(weights), int(bool(is_max))))
+
+    def set_seq1(self, seq1: bytes):
+        _check(lib.psa_group_set_seq1(self._h, seq1, len(seq1)))
+        self.n = len(seq1)
+
+    def set_seq2(self, seq2: bytes):
+        _check(lib.psa_group_set_seq2(self._h, seq2, len(seq2)))
+        self.m = len(seq2)
+
+    def search(self, first: Optional[int] = None, last: Optional[int] = None):
+        """-> (folded Result, [per-device Result])"""
+        first = 0 if first is None else first
+        last = self.n - self.m + 1 if last is None else last
+        out = Result()
+        shards = (Result * self.size())()
+        _check(lib.psa_search_sharded(self._h, first, last, C.byref(out), shards))
+        return out, list(shards)
 
 
 def search(seq1: bytes, seq2: bytes, weights: Sequence[float], is_max: bool,

@@ -438,6 +438,50 @@ def test_batch_kernel_barrier_timeout_is_retried(psa_debug, oracle, monkeypatch)
     assert [r.as_tuple() for r in again] == [r.as_tuple() for r in got]
 
 
+def test_sharded_search_through_the_c_abi(psa, oracle, reference_records):
+    """psa_search_sharded (the reference's MPI layer, cpu_funcs.c:49-94, behind the C ABI): contexts per device,
+    psa_shard_range split, ONE RCCL all-gather of the 32-byte records, psa_fold.  A one-GPU box can only form a
+    group of one device — the RCCL communicator, the exchange and the fold still run; N > 1 folds are covered by
+    the gloo tests and test_sub_ranges_and_shard_fold (same records, same fold)."""
+    w, s1, s2, is_max = reference_records[5]                  # the sequential-rounding trap: offset 9, not 2
+    with psa.Group([0]) as g:
+        assert g.size() == 1
+        g.set_weights(w, is_max)
+        g.set_seq1(s1)
+        g.set_seq2(s2)
+        res, shards = g.search()
+        assert_same(res, oracle.search(s1, s2, w, is_max, threads=4))
+        assert len(shards) == 1 and shards[0].shard == 0 and shards[0].offset == res.offset
+        assert res.pairs == (len(s1) - len(s2) + 1) * len(s2)
+        res, _ = g.search(100, 3000)
+        assert_same(res, oracle.search(s1, s2, w, is_max, 100, 3000, threads=4))
+        # a second Seq2 and mode on the same group
+        w0, s10, s20, max0 = reference_records[0]
+        g.set_weights(w0, max0)
+        g.set_seq1(s10)
+        g.set_seq2(s20)
+        res, _ = g.search()
+        assert (res.offset, res.char_offset, chr(res.ch), res.score) == (4505, 144, "E", -4879.0)
+        with pytest.raises(psa.PsaError):
+            g.search(5, 5)
+    with pytest.raises(psa.PsaError):
+        psa.Group([0, 0])                                     # a device listed twice
+
+
+def test_drop_in_program_with_psa_devices(psa, tmp_path):
+    """PSA_DEVICES routes the drop-in binary through the device group (here: a group of one)."""
+    import shutil
+    import subprocess
+    from conftest import PKG
+    exe = os.path.join(PKG, "host", "psa_main")
+    shutil.copy(os.path.join(GOLDEN, "reference_input.txt"), tmp_path / "input.txt")
+    env = dict(os.environ, PSA_DEVICES="0")
+    p = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "processes= 1" in p.stdout
+    assert (tmp_path / "output.txt").read_bytes() == open(os.path.join(GOLDEN, "reference_output.txt"), "rb").read()
+
+
 def test_filter_engine_synthetic_golden_and_ranges(psa, oracle):
     gold = json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))
     with psa.Context(0) as c:

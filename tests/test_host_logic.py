@@ -110,3 +110,13 @@ def test_no_device_fails_loudly(psa):
     with pytest.raises(psa.PsaError) as e:
         psa.Context(0)
     assert e.value.status == psa.PSA_ERR_DEVICE
+
+
+def test_group_needs_a_device(psa):
+    """psa_group_create fails loudly (PSA_ERR_DEVICE) without a HIP device; bad arguments are PSA_ERR_ARG."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present")
+    with pytest.raises(psa.PsaError) as e:
+        psa.Group([0])
+    assert e.value.status == psa.PSA_ERR_DEVICE
