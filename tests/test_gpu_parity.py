@@ -482,6 +482,25 @@ def test_drop_in_program_with_psa_devices(psa, tmp_path):
     assert (tmp_path / "output.txt").read_bytes() == open(os.path.join(GOLDEN, "reference_output.txt"), "rb").read()
 
 
+@pytest.mark.parametrize("arg,printed", [("37", 37), ("1", 1), ("99", 99), ("100", 100), (None, 100), ("250", 100)])
+def test_drop_in_program_hybrid_split(psa, oracle, reference_records, tmp_path, arg, printed):
+    """argv[1] = CUDA percentage (main.c:30-42, divide_execute_tasks cpu_funcs.c:137-214): the first share of the
+    offsets through gpu_run_program on thread 0, the rest on the program's host threads, GPU wins ties.  The merged
+    answer is the full search's for every split (records 0, 5 = rounding trap, 9 = 89 exact ties, 11 = six offsets)."""
+    import subprocess
+    from conftest import PKG
+    from test_host_logic import _write_record, _expected_output
+    exe = os.path.join(PKG, "host", "psa_main")
+    for rec in (0, 5, 9, 11):
+        d = tmp_path / f"rec{rec}"
+        d.mkdir()
+        _write_record(d / "input.txt", reference_records[rec])
+        run = subprocess.run([exe] + ([arg] if arg else []), cwd=d, capture_output=True, text=True, timeout=120)
+        assert run.returncode == 0, run.stdout + run.stderr
+        assert run.stdout.splitlines()[1] == f"CUDA percentage set to {printed}"
+        assert (d / "output.txt").read_text() == _expected_output(oracle, reference_records[rec]), rec
+
+
 def test_filter_engine_synthetic_golden_and_ranges(psa, oracle):
     gold = json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))
     with psa.Context(0) as c:

@@ -120,3 +120,43 @@ def test_group_needs_a_device(psa):
     with pytest.raises(psa.PsaError) as e:
         psa.Group([0])
     assert e.value.status == psa.PSA_ERR_DEVICE
+
+
+def _write_record(path, rec):
+    w, s1, s2, is_max = rec
+    with open(path, "w") as f:
+        f.write("%s %s %s %s\n%s\n%s\n%s\n" % (repr(w[0]), repr(w[1]), repr(w[2]), repr(w[3]), s1.decode(), s2.decode(),
+                                             "maximum" if is_max else "minimum"))
+
+
+def _expected_output(oracle, rec):
+    w, s1, s2, is_max = rec
+    score, off, ci, ch = oracle.search(s1, s2, w, is_max, threads=4)
+    mut = bytearray(s2)
+    mut[ci] = ord(ch)
+    return mut.decode() + "\n%d %s" % (off, "%g" % score)
+
+
+@pytest.mark.parametrize("arg", ["0", "-100"])
+def test_drop_in_program_cpu_share_only(psa, oracle, reference_records, tmp_path, arg):
+    """`psa_main 0` / `psa_main -100` (main.c:30-42): the whole search on the host threads of the program
+    (divide_execute_tasks with cuda_percentage 0, cpu_funcs.c:144-199) — no GPU needed.  output.txt of the bundled
+    input byte-for-byte; the other distinct records against the oracle (record 5: sequential-rounding trap)."""
+    import shutil
+    import subprocess
+    from conftest import GOLDEN, PKG, DISTINCT_RECORDS
+    exe = os.path.join(PKG, "host", "psa_main")
+    shutil.copy(os.path.join(GOLDEN, "reference_input.txt"), tmp_path / "input.txt")
+    run = subprocess.run([exe, arg], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert (tmp_path / "output.txt").read_bytes() == open(os.path.join(GOLDEN, "reference_output.txt"), "rb").read()
+    lines = run.stdout.splitlines()
+    assert lines[0] == ("threads= 1, processes= 1" if arg == "-100" else "threads= 4, processes= 1")
+    assert lines[1] == "CUDA percentage set to 0"
+    for rec in DISTINCT_RECORDS[1:]:
+        d = tmp_path / f"rec{rec}"
+        d.mkdir()
+        _write_record(d / "input.txt", reference_records[rec])
+        run = subprocess.run([exe, arg], cwd=d, capture_output=True, text=True, timeout=120)
+        assert run.returncode == 0, run.stdout + run.stderr
+        assert (d / "output.txt").read_text() == _expected_output(oracle, reference_records[rec]), rec
