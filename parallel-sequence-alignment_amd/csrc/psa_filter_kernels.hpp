@@ -997,6 +997,8 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     __shared__ unsigned char      s_clsrank[kRow * kRow];
     __shared__ __attribute__((aligned(16))) unsigned char s_codes[kRescoreChunk + 64 * kRescoreEpl + 16];
     __shared__ double             s_vals[64];
+    __shared__ double             s_class[8];     // the class values, indexable (a by-value kernel argument indexed
+                                                  // at run time would be copied to scratch by every lane)
     __shared__ long long          s_round[8];
     __shared__ unsigned long long s_key[kRescoreThreads / 64];
     __shared__ int s_last;
@@ -1042,6 +1044,10 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     }
     if ((int)blockIdx.x >= count) return;
     for (int k = tid; k < kRow * kRow; k += kRescoreThreads) s_clsrank[k] = a.clsrank[k];
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_class[k] = a.class_value[k];
+    }
     __syncthreads();
     const double final_best = key_order(*a.global_best);
     PSA_RPHASE(1);
@@ -1095,7 +1101,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
                     long long r = 0;
                     bool tie = false;
                     if (lane < 5) {
-                        const unsigned long long pb = (unsigned long long)__double_as_longlong(a.class_value[lane]);
+                        const unsigned long long pb = (unsigned long long)__double_as_longlong(s_class[lane]);
                         const int ep = (int)((pb >> 52) & 0x7ff);
                         if (ep != 0) {                           // zero stays 0 (subnormals excluded by fast_ok)
                             const unsigned long long mp = (pb & 0xfffffffffffffull) | (1ull << 52);
@@ -1114,7 +1120,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
                 if (!walk) {
                     // plain chain over the next <= 64 chars; lanes past the chunk hold +0.0 (exact to add)
                     const int nb = c1 - k < 64 ? c1 - k : 64;
-                    s_vals[lane] = lane < nb ? a.class_value[s_codes[k - c0 + lane] & 7u] : 0.0;
+                    s_vals[lane] = lane < nb ? s_class[s_codes[k - c0 + lane] & 7u] : 0.0;
                     __builtin_amdgcn_wave_barrier();
                     const double2* v = reinterpret_cast<const double2*>(s_vals);   // same address in every lane: broadcast
 #pragma unroll
@@ -1189,7 +1195,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
                                                      (mag & 0xfffffffffffffull)));
                 if (left) {
                     // this char moves the sum out of the binade: one true fp64 add
-                    s += a.class_value[s_codes[k - c0] & 7u];
+                    s += s_class[s_codes[k - c0] & 7u];
                     k += 1;
                 }
                 __builtin_amdgcn_wave_barrier();
