@@ -67,6 +67,8 @@ def parse_args(argv=None):
                     help="N > 1, batch mode: weak = Q queries per rank, strong = Q queries dealt to the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--batch-streams", type=int, default=1, choices=(1, 2),
+                    help="2: a batch's count launches alternate between two streams (psa_set_batch_streams)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="analysis only: time rank 0's share of a W-rank strong-scaling run on one GPU (no collective)")
     ap.add_argument("--stub-search", action="store_true",
@@ -264,6 +266,7 @@ def main():
     stream = torch.cuda.current_stream(device)
     ctx = psa.Context(local_rank, stream.cuda_stream)
     ctx.set_engine(args.engine)
+    ctx.set_batch_streams(args.batch_streams)
     ctx.set_weights(WEIGHTS, True)
 
     if args.mode == "batch":

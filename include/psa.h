@@ -114,6 +114,9 @@ psa_status psa_set_seq1_device(psa_context* ctx, const void* d_seq1, int n);
 psa_status psa_set_seq2_device(psa_context* ctx, const void* d_seq2, int m);
 
 psa_status psa_set_engine(psa_context* ctx, psa_engine engine);
+/* Batches: count launches stay on one stream (default 1: no two launches overlap, a profiler sees each launch's
+ * own duration) or alternate between two (2: consecutive launches overlap at their edges). */
+psa_status psa_set_batch_streams(psa_context* ctx, int streams);
 
 /* Search offsets [first_offset, last_offset) — the body of gpu_run_program.
  * psa_search blocks; psa_search_async enqueues on the context's stream and

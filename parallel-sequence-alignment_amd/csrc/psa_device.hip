@@ -383,7 +383,7 @@ struct psa_context {
     hipStream_t stream = nullptr;      // main stream (caller's or owned)
     hipStream_t aux = nullptr;         // owned: tails of batched searches
     hipStream_t twin = nullptr;        // owned: every other count kernel of a pooled batch (kernels overlap at their edges)
-    int batch_streams = 2;
+    int batch_streams = 1;             // count launches of a batch on one stream (2: alternate between two, psa_set_batch_streams)
     int batch_rescore_grid = 8;        // re-score workgroups per query inside a batch (the CUs are busy counting)
     int granted16 = 0, granted8 = 0;   // dynamic-LDS grants of the count kernels on this context's device
     bool granted_duo = false;
@@ -1035,12 +1035,12 @@ bool use_filter(const psa_context* c, int first, int last, int m)
     FilterPlan p;
     if (!plan_filter(first, last, m, &p)) return false;      // Seq2 beyond what the count kernels chunk
     if (c->engine == PSA_ENGINE_FILTER) return true;
-    // Measured on MI355X (tools/engine_threshold.py), microseconds per blocking search: the sequential engine
-    // is a serial chain of m additions per lane, the filter engine has the larger fixed cost (two kernels,
-    // plane build, epilogue) and 15x the throughput.
+    // Measured on MI355X (tools/engine_threshold.py, round 2 kernels), microseconds per blocking search: the
+    // sequential engine is a serial chain of m additions per lane, the filter engine has the larger fixed cost
+    // (two kernels, plane build, epilogue) and ~16x the throughput.
     const double pairs = (double)(last - first) * m;
-    const double t_sequential = 25.0 + 0.034 * m + pairs / 5.9e6;
-    const double t_filter = 45.0 + 0.0125 * m + pairs / 6.0e7;
+    const double t_sequential = 22.0 + 0.034 * m + pairs / 8.5e6;
+    const double t_filter = 42.0 + 0.0037 * m + pairs / 1.4e8;
     return t_filter < t_sequential;
 }
 
@@ -1275,6 +1275,16 @@ psa_status psa_set_seq2(psa_context* c, const char* seq2, int m)
     PSA_TRY(encode_seq2(c, c->slot[0], c->d_raw, m, c->stream));
     PSA_TRY(check_bad_now(c));
     return report_bad(c);
+}
+
+// Count launches of a batch run on one stream by default; 2 alternates them between two streams (the next launch's
+// workgroups fill the CUs the running one leaves idle at its edges: worth 9 % with the round-1 kernels, within
+// noise with the round-2 ones, whose launches are back to back on 244 of 256 CUs).
+psa_status psa_set_batch_streams(psa_context* c, int streams)
+{
+    if (!c || streams < 1 || streams > 2) { set_last_error("psa_set_batch_streams: 1 or 2"); return PSA_ERR_ARG; }
+    c->batch_streams = streams;
+    return PSA_OK;
 }
 
 psa_status psa_set_engine(psa_context* c, psa_engine engine)

@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "gpu_run_program", "gpu_run_program_layout",
     "psa_create", "psa_destroy", "psa_set_weights",
     "psa_set_seq1", "psa_set_seq2", "psa_set_seq1_device", "psa_set_seq2_device",
-    "psa_set_engine", "psa_search", "psa_search_async", "psa_search_wait", "psa_scores",
+    "psa_set_engine", "psa_set_batch_streams", "psa_search", "psa_search_async", "psa_search_wait", "psa_scores",
     "psa_search_batch", "psa_search_batch_device",
     "psa_search_batch_minmax", "psa_search_batch_minmax_device",
     "psa_debug_counts", "psa_fallback_count", "psa_reselect_count", "psa_duo_retry_count", "psa_debug_rescore",
@@ -80,6 +80,7 @@ def _load() -> C.CDLL:
     lib.psa_set_seq1_device.argtypes = [vp, vp, i]
     lib.psa_set_seq2_device.argtypes = [vp, vp, i]
     lib.psa_set_engine.argtypes = [vp, i]
+    lib.psa_set_batch_streams.argtypes = [vp, i]
     lib.psa_search.argtypes = [vp, i, i, C.POINTER(Result)]
     lib.psa_search_async.argtypes = [vp, i, i]
     lib.psa_search_wait.argtypes = [vp, C.POINTER(Result)]
@@ -226,6 +227,9 @@ class Context:
 
     def set_engine(self, engine: int):
         _check(lib.psa_set_engine(self._h, engine))
+
+    def set_batch_streams(self, streams: int):
+        _check(lib.psa_set_batch_streams(self._h, streams))
 
     def total_offsets(self) -> int:
         return self.n - self.m + 1

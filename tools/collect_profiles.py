@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""Condenses rocprofv3 output dirs (gpurun_out/prof_*) into committed summaries.
+"""Condenses rocprofv3 output dirs under gpurun_out/ into committed summaries.
 
-  python tools/collect_profiles.py <tag>      e.g. r01_seq
-writes profiles/<tag>_kernel_stats.csv  (rocprofv3 --kernel-trace --stats summary, verbatim; from prof_stats/)
-       profiles/<tag>_twin_kernel_stats.csv  (the same from prof_stats_twin/, if present)
-       profiles/<tag>_counters.csv      (mean of every PMC counter per kernel, one pass per counter set)
-and updates profiles/hbm_traffic.json   (per-launch HBM bytes of each psa kernel:
+  python tools/collect_profiles.py <tag> [<prefix>]     e.g. r02 prof_r02
+reads  gpurun_out/<prefix>_stats/      rocprofv3 --kernel-trace --stats  (bench.py --batch-streams 1)
+       gpurun_out/<prefix>_twin/       the same with the default two streams
+       gpurun_out/<prefix>_pmc*/       rocprofv3 --pmc ... passes (one counter set each)
+writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_twin_kernel_stats.csv (verbatim rocprofv3 summaries),
+       profiles/<tag>_counters.csv   (kernel, counter, dispatches, mean_per_dispatch — every (kernel, counter) pair
+                                      from its own rows of its own pass),
+and updates profiles/hbm_traffic.json (per-launch HBM bytes of each psa kernel:
        (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — FETCH_SIZE/WRITE_SIZE are in KiB and gfx950's FETCH_SIZE
        reports half of the fetched bytes, MI355X_MICROARCH.md §HBM; the x2 is calibrated there for
-       16 B/lane streams, this kernel reads 4 B/lane, so treat the absolute as +-2x).
+       16 B/lane streams, these kernels read 4-16 B/lane, so treat the absolute as +-2x).
 """
 import collections
 import csv
@@ -24,24 +27,22 @@ OUT = os.path.join(ROOT, "profiles")
 
 def main():
     tag = sys.argv[1]
+    prefix = sys.argv[2] if len(sys.argv) > 2 else "prof_" + tag
     src = os.path.join(ROOT, "gpurun_out")
     os.makedirs(OUT, exist_ok=True)
-    stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))
-    if stats:
-        shutil.copy(stats[0], os.path.join(OUT, f"{tag}_kernel_stats.csv"))
-    # the default batch (count kernels of consecutive queries overlap on two streams)
-    twin = glob.glob(os.path.join(src, "prof_stats_twin", "*", "*_kernel_stats.csv"))
-    if twin:
-        shutil.copy(twin[0], os.path.join(OUT, f"{tag}_twin_kernel_stats.csv"))
+    for sub, name in (("_stats", f"{tag}_kernel_stats.csv"), ("_twin", f"{tag}_twin_kernel_stats.csv")):
+        stats = glob.glob(os.path.join(src, prefix + sub, "*", "*_kernel_stats.csv"))
+        if stats:
+            shutil.copy(stats[0], os.path.join(OUT, name))
     acc = collections.defaultdict(list)
-    for f in glob.glob(os.path.join(src, "prof_*", "*", "*_counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(src, prefix + "_pmc*", "*", "*_counter_collection.csv"))):
         for row in csv.DictReader(open(f)):
             acc[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
     with open(os.path.join(OUT, f"{tag}_counters.csv"), "w", newline="") as fh:
         w = csv.writer(fh)
         w.writerow(["kernel", "counter", "dispatches", "mean_per_dispatch"])
         for (k, c), v in sorted(acc.items()):
-            if k.startswith("__amd_rocclr"):
+            if k.startswith("__amd_rocclr") or "psa" not in k:
                 continue
             w.writerow([k, c, len(v), sum(v) / len(v)])
     tpath = os.path.join(OUT, "hbm_traffic.json")
