@@ -336,32 +336,39 @@ __device__ __forceinline__ void count_classes(Counter (&cnt)[2][kCounters],
 {
     // the row offsets of a round are fetched one round ahead, the LDS slots one char ahead;
     // the last prefetches of a wave run past its range into valid padding and are never used
-    unsigned rowoff[kUnroll], rowoff_next[kUnroll];
+    // two sets of row offsets: a round reads one while the next round's arrive in the other (no copies;
+    // the code-byte budget of this loop is what bounds it)
+    unsigned rowoff_a[kUnroll], rowoff_b[kUnroll];
 #pragma unroll
-    for (int q = 0; q < kUnroll; ++q) rowoff[q] = row_of(sym[q]);
+    for (int q = 0; q < kUnroll; ++q) rowoff_a[q] = row_of(sym[q]);
     unsigned lane_addr;
     SlotRegs cur;
-    // one round; `how` is what becomes of its carry (CarryUse)
-    auto round = [&](auto how) {
-        sym += kUnroll;
-#pragma unroll
-        for (int q = 0; q < kUnroll; ++q) rowoff_next[q] = row_of(sym[q]);   // wave-uniform
-        class_round<decltype(how)::value>(cnt, cur, rowoff, rowoff_next[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
-#pragma unroll
-        for (int q = 0; q < kUnroll; ++q) rowoff[q] = rowoff_next[q];
-        lane_addr += 8u * kUnroll;
-    };
     for (int c = 0; c < nclasses; ++c) {
         if (c) shift_planes(cnt, 1u, lane);              // Horner step: C[x] <- C[x+1], then add the next class
         lane_addr = lane_base;
-        lds_issue<0>(cur, lane_addr + rowoff[0]);
+        lds_issue<0>(cur, lane_addr + rowoff_a[0]);
         lds_retire(cur);
         int g = 0;
         for (; g + 2 * kUnroll <= class_chars; g += 2 * kUnroll) {
-            round(std::integral_constant<int, kHold>{});
-            round(std::integral_constant<int, kJoin>{});
+            sym += kUnroll;
+#pragma unroll
+            for (int q = 0; q < kUnroll; ++q) rowoff_b[q] = row_of(sym[q]);   // wave-uniform
+            class_round<kHold>(cnt, cur, rowoff_a, rowoff_b[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
+            lane_addr += 8u * kUnroll;
+            sym += kUnroll;
+#pragma unroll
+            for (int q = 0; q < kUnroll; ++q) rowoff_a[q] = row_of(sym[q]);
+            class_round<kJoin>(cnt, cur, rowoff_b, rowoff_a[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
+            lane_addr += 8u * kUnroll;
         }
-        if (g < class_chars) round(std::integral_constant<int, kAlone>{});
+        if (g < class_chars) {                           // a class's odd last round
+            sym += kUnroll;
+#pragma unroll
+            for (int q = 0; q < kUnroll; ++q) rowoff_b[q] = row_of(sym[q]);
+            class_round<kAlone>(cnt, cur, rowoff_a, rowoff_b[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
+#pragma unroll
+            for (int q = 0; q < kUnroll; ++q) rowoff_a[q] = rowoff_b[q];
+        }
     }
     if (low_class) shift_planes(cnt, low_class, lane);
 }

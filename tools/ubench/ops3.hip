@@ -26,6 +26,10 @@ __global__ __launch_bounds__(1024) void k(unsigned* out, int iters)
         if (OP == 5) asm volatile(R64("v_alignbit_b32 v20, v9, v8, 7\n v_alignbit_b32 v21, v11, v10, 7\n v_and_b32 v24, v20, v21\n v_bitop3_b32 v16, v16, v20, v24 bitop3:0x96\n") ::: CLOB);
         // 6: v_xor_b32 e32 accumulate
         if (OP == 6) asm volatile(R64("v_xor_b32 v16, v16, v9\n v_xor_b32 v17, v17, v10\n v_xor_b32 v18, v18, v11\n v_xor_b32 v19, v19, v12\n") ::: CLOB);
+        // 7: the same v_xor in its 8-byte VOP3 encoding: does the rate follow the code bytes (instruction fetch)?
+        if (OP == 7) asm volatile(R64("v_xor_b32_e64 v16, v16, v9\n v_xor_b32_e64 v17, v17, v10\n v_xor_b32_e64 v18, v18, v11\n v_xor_b32_e64 v19, v19, v12\n") ::: CLOB);
+        // 8: half 4-byte, half 8-byte
+        if (OP == 8) asm volatile(R64("v_xor_b32 v16, v16, v9\n v_bitop3_b32 v17, v17, v10, v11 bitop3:0x96\n v_xor_b32 v18, v18, v11\n v_bitop3_b32 v19, v19, v12, v13 bitop3:0xe8\n") ::: CLOB);
     }
     unsigned r;
     asm volatile("v_xor_b32 %0, v16, v17" : "=v"(r));
@@ -54,5 +58,7 @@ int main()
     run<4>("alignbit x4");
     run<5>("alignbit, alignbit, and, bitop3 (dependent)");
     run<6>("v_xor_b32 accumulate");
+    run<7>("v_xor_b32_e64 (8-byte encoding) accumulate");
+    run<8>("v_xor_b32 e32 / v_bitop3_b32 alternating");
     return 0;
 }
