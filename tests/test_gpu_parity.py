@@ -754,7 +754,7 @@ def test_batch_shapes_against_sequential_engine(psa):
     rng = np.random.default_rng(77)
     key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
     shapes = [(70_000, 31, 3), (70_000, 256, 2), (70_000, 257, 5), (120_000, 1023, 4), (120_000, 1024, 3),
-              (200_000, 5000, 7), (300_000, 12_256, 3), (300_000, 12_257, 2), (300_000, 16_128, 2),
+              (200_000, 5000, 7), (300_000, 11_264, 3), (300_000, 11_265, 2), (300_000, 12_257, 2), (300_000, 16_128, 2),
               (90_000, 40_000, 2), (1_000_000, 700, 33), (50_000, 8, 9)]
     with psa.Context(0) as cf, psa.Context(0) as cs:
         cf.set_engine(psa.ENGINE_FILTER)
@@ -842,10 +842,9 @@ def test_drop_in_program_pretty_view(psa, oracle, reference_records, tmp_path):
 
 
 def test_long_seq2_multi_chunk_path(psa, oracle):
-    """|Seq2| above one workgroup's reach (16 waves x 992 chars): several char chunks, partial counts
-    whose
-    workgroups combine their partial counts inside the count kernel (last arriver per tile); also a short range
-    that spreads chunks to fill the GPU."""
+    """|Seq2| above one workgroup's reach (32 shift classes x 352 chars): several char chunks whose workgroups
+    combine their partial counts inside the count kernel (last arriver per tile); also a short range that spreads
+    chunks to fill the GPU."""
     s1 = psa.generate_sequence(91, 60000)
     s2 = psa.generate_sequence(92, 20011)
     for is_max in (True, False):
