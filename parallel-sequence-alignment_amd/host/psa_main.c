@@ -28,6 +28,11 @@
  * first) and writes one "<mutated seq2>\n<offset> <score>" block per record,
  * blocks separated by a newline.
  *
+ * `psa_main --table` prints the 27x27 sign table (A..Z and '-') in the layout of
+ * the reference's print_hash (cpu_funcs.c:322-349; README.md:105-133 shows it
+ * with '_' as blanks) and exits: the table comes from the library's host-side
+ * builder (psa_build_tables), no device needed.
+ *
  * Extension: `psa_main --pretty [percentage]` also prints the
  * reference's human-checkable view of the answer (pretty_print,
  * cpu_funcs.c:382-426, its DEBUG_PRINT build): mode, weights, the score and
@@ -253,6 +258,30 @@ static void pretty_print(const ProgramData* data, const char* mut, int offset, i
     printf("Seq offset=%3d, Char offset=%3d\n", offset, char_offset);
 }
 
+/* the sign table as print_hash lays it out (cpu_funcs.c:322-349): header, rule, one row per symbol */
+static int print_sign_table(void)
+{
+    static const char symbols[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZ-";
+    const double unit[PSA_NUM_WEIGHTS] = {1, 1, 1, 1};     /* the signs do not depend on the weights */
+    const int count = (int)(sizeof symbols - 1);
+    int r, c;
+    if (psa_build_tables(unit, 1, NULL, NULL, NULL, g_sign) != PSA_OK) {
+        fprintf(stderr, "%s\n", psa_last_error());
+        return 1;
+    }
+    printf("   ");
+    for (c = 0; c < count; ++c) printf(c + 1 < count ? "%c " : "%c\n", symbols[c]);
+    printf("   ");
+    for (c = 0; c < count; ++c) printf("__");
+    printf("\n");
+    for (r = 0; r < count; ++r) {
+        printf("%c |", symbols[r]);
+        for (c = 0; c < count; ++c) printf("%c ", g_sign[symbol_index(symbols[r]) * 32 + symbol_index(symbols[c])]);
+        printf("\n");
+    }
+    return 0;
+}
+
 static int run_all_records(void)
 {
     FILE* in = fopen(PSA_INPUT_FILE, "r");
@@ -314,6 +343,7 @@ int main(int argc, char* argv[])
     const char* percentage = argc == 2 ? argv[1] : NULL;
 
     if (argc == 2 && strcmp(argv[1], "--all") == 0) return run_all_records();
+    if (argc == 2 && strcmp(argv[1], "--table") == 0) return print_sign_table();
     if (argc >= 2 && strcmp(argv[1], "--pretty") == 0) {
         pretty = 1;
         percentage = argc == 3 ? argv[2] : NULL;

@@ -160,3 +160,17 @@ def test_drop_in_program_cpu_share_only(psa, oracle, reference_records, tmp_path
         run = subprocess.run([exe, arg], cwd=d, capture_output=True, text=True, timeout=120)
         assert run.returncode == 0, run.stdout + run.stderr
         assert (d / "output.txt").read_text() == _expected_output(oracle, reference_records[rec]), rec
+
+
+def test_drop_in_program_sign_table(psa):
+    """`psa_main --table`: the 27x27 sign table in print_hash's layout (cpu_funcs.c:322-349) equals the README's
+    golden table (README.md:105-133, which shows '_' as blanks) — no device needed."""
+    import subprocess
+    from conftest import GOLDEN, PKG
+    run = subprocess.run([os.path.join(PKG, "host", "psa_main"), "--table"], capture_output=True, text=True, timeout=60)
+    assert run.returncode == 0, run.stderr
+    got = [ln.replace("_", " ").rstrip() for ln in run.stdout.splitlines()[2:]]
+    want = [ln.rstrip() for ln in open(os.path.join(GOLDEN, "readme_sign_table.txt")).read().split("\n") if ln.strip()]
+    want = [ln for ln in want if "|" in ln]
+    assert len(got) == 27 and got == want
+    assert run.stdout.splitlines()[0].split() == list("ABCDEFGHIJKLMNOPQRSTUVWXYZ-")
