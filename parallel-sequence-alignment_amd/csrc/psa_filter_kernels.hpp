@@ -1148,22 +1148,33 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
                 // |q| strictly inside (2^52, 2^53)  <=>  q strictly inside (bound_lo, bound_hi)
                 const long long bound_lo = neg ? -(1ll << 53) : (1ll << 52);
                 const long long bound_hi = neg ? -(1ll << 52) : (1ll << 53);
-                static_assert(kRescoreEpl == 8, "a lane's codes of one batch are one 8-byte LDS word");
+                static_assert(kRescoreEpl % 8 == 0 && kRescoreEpl <= 16, "a lane's codes of one batch are 8-byte LDS words");
+                constexpr int kWords = kRescoreEpl / 8;
                 bool left = false;
                 while (k < c1 && !left) {
-                    // The batch starts at the 8-aligned position at or below k; chars below k are already in
-                    // S and count as padding (class 4, addend 0), like the staged positions past c1.
-                    const int k_al = k & ~7;
-                    unsigned long long w = *reinterpret_cast<const unsigned long long*>(s_codes + (k_al - c0) + lane * 8);
+                    // The batch starts at the kRescoreEpl-aligned position at or below k; chars below k are already
+                    // in S and count as padding (class 4, addend 0), like the staged positions past c1.
+                    const int k_al = k & ~(kRescoreEpl - 1);
+                    unsigned long long w[kWords];
+#pragma unroll
+                    for (int x = 0; x < kWords; ++x)
+                        w[x] = *reinterpret_cast<const unsigned long long*>(s_codes + (k_al - c0) + lane * kRescoreEpl + 8 * x);
                     if (lane == 0 && k != k_al) {
-                        const unsigned long long keep = ~0ull << (8 * (k - k_al));
-                        w = (w & keep) | (0x0404040404040404ull & ~keep);
+#pragma unroll
+                        for (int x = 0; x < kWords; ++x) {
+                            const int skip = k - k_al - 8 * x;                  // chars of this word already summed
+                            if (skip >= 8) w[x] = 0x0404040404040404ull;
+                            else if (skip > 0) {
+                                const unsigned long long keep = ~0ull << (8 * skip);
+                                w[x] = (w[x] & keep) | (0x0404040404040404ull & ~keep);
+                            }
+                        }
                     }
                     long long rr[kRescoreEpl];
                     long long t = 0;
 #pragma unroll
                     for (int j = 0; j < kRescoreEpl; ++j) {
-                        rr[j] = s_round[(unsigned)(w >> (8 * j)) & 7u];
+                        rr[j] = s_round[(unsigned)(w[j >> 3] >> (8 * (j & 7))) & 7u];
                         t += rr[j];
                     }
                     const long long incl = wave_scan_inclusive(t);
