@@ -224,7 +224,7 @@ extern "C" {
 
 const char* psa_last_error(void) { return psa::g_last_error.c_str(); }
 
-const char* psa_version(void) { return "psa_amd 0.1 (gfx950)"; }
+const char* psa_version(void) { return "psa_amd 0.2 (gfx950)"; }
 
 psa_status psa_build_tables(const double weights[4], int is_max,
                             double* P, unsigned char* SUB, double* DELTA, char* SIGN)
