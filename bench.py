@@ -71,6 +71,10 @@ def parse_args(argv=None):
                     help="2: a batch's count launches alternate between two streams (psa_set_batch_streams)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="analysis only: time rank 0's share of a W-rank strong-scaling run on one GPU (no collective)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="collective backend of the record exchange (gloo: rehearsal, records travel through host memory)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a one-GPU box: every rank uses device 0 (needs --backend gloo; not a scaling measurement)")
     ap.add_argument("--stub-search", action="store_true",
                     help="launcher / exchange rehearsal without a GPU: gloo, records made up from the query index")
     return ap.parse_args(argv)
@@ -85,7 +89,7 @@ def self_launch(args):
     if not args.stub_search:
         import torch
         have = torch.cuda.device_count()
-        if have < args.gpus:
+        if have < (1 if args.share_gpu else args.gpus):
             print(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) visible", file=sys.stderr)
             return 2
     with socket.socket() as s:
@@ -239,15 +243,22 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.share_gpu:
+        if args.backend != "gloo":
+            raise SystemExit("bench.py: --share-gpu is a rehearsal and needs --backend gloo (RCCL wants one GPU per rank)")
+        local_rank = 0
     if torch.cuda.device_count() <= local_rank:
         raise SystemExit(f"bench.py: rank {rank} has no device {local_rank} ({torch.cuda.device_count()} visible)")
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
+    xdev = device if args.backend == "nccl" else torch.device("cpu")       # where the exchanged records live
+    if world > 1:
+        import torch.distributed as dist
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
     n, m = args.n, args.m
     total = n - m + 1
@@ -280,7 +291,7 @@ def main():
             ctx.set_seq1_device(t1.data_ptr(), n)          # from raw ASCII: encode, once per batch
             mine = ctx.search_batch_device(tq[qlo].data_ptr(), qhi - qlo, m, m) if qhi > qlo else []
             if world > 1:
-                return gather_records(psa, dist, torch, mine, slot0, total_q, device)
+                return gather_records(psa, dist, torch, mine, slot0, total_q, xdev)
             return mine
     else:
         first, last = psa.shard_range(total, eff_world, eff_rank)
@@ -291,7 +302,7 @@ def main():
             ctx.set_seq2_device(tq[0].data_ptr(), m)
             rec = ctx.search(first, last)
             if world > 1:
-                rec = exchange_and_fold(psa, dist, torch, rec, rank, world, True, device)
+                rec = exchange_and_fold(psa, dist, torch, rec, rank, world, True, xdev)
             return [rec]
 
     def timed(fn, steps):
@@ -306,7 +317,7 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         if dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=xdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         return elapsed, out
@@ -326,7 +337,7 @@ def main():
             ctx.set_seq1_device(t1.data_ptr(), n)
             hi, lo = ctx.search_batch_minmax_device(tq[qlo].data_ptr(), qhi - qlo, m, m) if qhi > qlo else ([], [])
             if world > 1:
-                return gather_records(psa, dist, torch, hi + lo, 2 * slot0, 2 * total_q, device)
+                return gather_records(psa, dist, torch, hi + lo, 2 * slot0, 2 * total_q, xdev)
             return hi + lo
         step_minmax()
         mm_elapsed, mm = timed(step_minmax, args.steps)
@@ -526,7 +537,9 @@ def main():
             "offsets_per_query": total, "queries_per_step": (total_q if args.mode == "batch" else 1),
             "pairs_per_step": pairs_step,
             "parallelism": (f"query-shard x{world}" if args.mode == "batch" else f"offset-shard x{world}"),
-            "exchange": "none" if world == 1 else "1 RCCL all-reduce(sum) of one-hot int64 records per step",
+            "exchange": "none" if world == 1 else
+                        ("1 RCCL all-reduce(sum) of one-hot int64 records per step" if args.backend == "nccl" else
+                         "REHEARSAL: gloo all-reduce through host memory" + (", all ranks on one GPU" if args.share_gpu else "")),
             "timed_region": "raw ASCII in HBM -> encode -> search -> records on host"},
         "result_query0": {"offset": q0.offset, "char_offset": q0.char_offset,
                           "ch": chr(q0.ch) if q0.ch else "", "score": q0.score},

@@ -501,6 +501,30 @@ def test_drop_in_program_hybrid_split(psa, oracle, reference_records, tmp_path, 
         assert (d / "output.txt").read_text() == _expected_output(oracle, reference_records[rec]), rec
 
 
+@pytest.mark.parametrize("extra", [["--scaling", "weak"], ["--scaling", "strong"], ["--mode", "shard"]])
+def test_bench_n_rank_paths_rehearsed_on_one_gpu(psa, extra):
+    """bench.py's N > 1 code paths on real hardware as far as a one-GPU box allows: `--gpus 2` launches two ranks
+    itself, both use device 0, the records travel through gloo (RCCL wants one GPU per rank).  The rank-0 line must
+    report n_gpus = 2, pass its own self-check (query 0 against the committed goldens, batch == single searches) and
+    give the configs[2] answer."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "1",
+           "--warmup", "1", "--queries", "16", "--no-cpu-baseline"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    line = json.loads([ln for ln in run.stdout.splitlines() if ln.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 2
+    assert line["result_query0"] == {"offset": 870261, "char_offset": 2, "ch": "A", "score": -3265.7999999995977}
+    if "--mode" not in extra:
+        v = line["verified"]
+        assert v["query0_max_equals_golden"] and v["query0_min_equals_golden"] and v["batch_from_host_equals_batch"]
+        assert v["batch_equals_single_search_queries"] > 0 and v["sequential_engine_fallbacks"] == 0
+        assert line["config"]["queries_per_step"] == (32 if extra[1] == "weak" else 16)
+
+
 def test_filter_engine_synthetic_golden_and_ranges(psa, oracle):
     gold = json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))
     with psa.Context(0) as c:
