@@ -16,6 +16,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
 alphabets = [b"ABCDEFGHIJKLMNOPQRSTUVWXYZ", b"ACDEFGHIKLMNPQRSTVWY", b"ACGT", b"AL-", b"NDEQKSTA-MILV", b"AB"]
 t_end = time.time() + budget
+t_note = time.time() + 60.0
 cases = 0
 with psa.Context(0) as cf, psa.Context(0) as cs, psa.Context(0) as ca:      # ca: PSA_ENGINE_AUTO
     cf.set_engine(psa.ENGINE_FILTER)
@@ -53,4 +54,7 @@ with psa.Context(0) as cf, psa.Context(0) as cs, psa.Context(0) as ca:      # ca
                 cs.set_seq2(q)
                 assert key(r) == key(cs.search(first, last)), ("vs sequential", n, m, nq, w, first, last, mode)
         cases += 1
+        if time.time() > t_note:                      # a sign of life every minute (long silent runs get killed)
+            print(f"soak: {cases} cases so far", flush=True)
+            t_note = time.time() + 60.0
     print(f"soak: {cases} random cases ok, {cf.fallback_count()} filter fallbacks (ties), {cf.reselect_count()} reselects")
