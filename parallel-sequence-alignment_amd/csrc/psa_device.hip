@@ -800,6 +800,16 @@ psa::BoundParams bound_params(const psa::Tables& t, int m)
         b.class_worst[i] = t.class_worst_delta[i];
     }
     b.slack = filter_slack(t, m);
+    {   // offset_bounds' fold over the classes, for an offset in which all four occur (same operations, same order)
+        const bool mx = t.is_max != 0;
+        double d_opt = mx ? -INFINITY : INFINITY, d_pes = d_opt;
+        for (int k = 0; k < 4; ++k) {
+            d_opt = mx ? std::fmax(d_opt, b.class_best[k]) : std::fmin(d_opt, b.class_best[k]);
+            d_pes = mx ? std::fmax(d_pes, b.class_worst[k]) : std::fmin(d_pes, b.class_worst[k]);
+        }
+        b.opt_all = d_opt;
+        b.pes_all = d_pes;
+    }
     b.m = m;
     b.is_max = t.is_max;
     return b;

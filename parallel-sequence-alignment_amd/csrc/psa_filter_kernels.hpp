@@ -442,6 +442,8 @@ struct BoundParams {
     double class_best[4];    // most favourable substitution delta inside each class
     double class_worst[4];   // least favourable delta inside each class
     double slack;            // rounding bound of the sequential sum + this formula
+    double opt_all, pes_all; // the best / worst delta over all four classes: what offset_bounds finds whenever every
+                             // class occurs at least once in an offset (always, for long random sequences)
     int m;
     int is_max;
 };
@@ -460,6 +462,9 @@ __device__ __forceinline__ double key_order(unsigned long long k)
 
 // optimistic ("upper") and pessimistic score of an offset in "bigger is better" form
 // (MIN searches are negated), each widened by the rounding slack
+// ALL_PRESENT: the caller has checked that all four classes occur in this offset (then the fold over the
+// classes that occur is the fold over all of them, precomputed by the host with the same operations).
+template <bool ALL_PRESENT>
 __device__ __forceinline__ void offset_bounds(const BoundParams& b, int n_lo, int n_hi, int n_both,
                                               double& upper, double& pess)
 {
@@ -467,17 +472,57 @@ __device__ __forceinline__ void offset_bounds(const BoundParams& b, int n_lo, in
     const int n0 = n_lo - n_both, n1 = n_hi - n_both, n2 = n_both;   // stars, colons, dots
     const int n3 = b.m - n0 - n1 - n2;
     const double total = ((b.w[0] * n0 - b.w[1] * n1) - b.w[2] * n2) - b.w[3] * n3;
-    const int n[4] = {n0, n1, n2, n3};
-    double d_opt = mx ? -INFINITY : INFINITY, d_pes = mx ? -INFINITY : INFINITY;
+    double d_opt, d_pes;
+    if constexpr (ALL_PRESENT) {
+        d_opt = b.opt_all;
+        d_pes = b.pes_all;
+    } else {
+        const int n[4] = {n0, n1, n2, n3};
+        d_opt = d_pes = mx ? -INFINITY : INFINITY;
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-        if (n[k] > 0) {
-            d_opt = mx ? fmax(d_opt, b.class_best[k]) : fmin(d_opt, b.class_best[k]);
-            d_pes = mx ? fmax(d_pes, b.class_worst[k]) : fmin(d_pes, b.class_worst[k]);
-        }
+        for (int k = 0; k < 4; ++k)
+            if (n[k] > 0) {
+                d_opt = mx ? fmax(d_opt, b.class_best[k]) : fmin(d_opt, b.class_best[k]);
+                d_pes = mx ? fmax(d_pes, b.class_worst[k]) : fmin(d_pes, b.class_worst[k]);
+            }
+    }
     const double sgn = mx ? 1.0 : -1.0;
     upper = sgn * (total + d_opt) + b.slack;
     pess = sgn * (total + d_pes) - b.slack;
+}
+
+// does every class occur in the offset with these counts?
+__device__ __forceinline__ bool all_classes_present(int m, unsigned n_lo, unsigned n_hi, unsigned n_both)
+{
+    return n_lo > n_both && n_hi > n_both && n_both > 0u && n_lo + n_hi < (unsigned)m + n_both;
+}
+
+// Score intervals of a thread's PER offsets (index o0 + e relative to the searched range, valid while below
+// `limit` offsets of the tile and inside [0, span)); returns the thread's best pessimistic bound.  The whole
+// wave takes the short path when every class occurs in every one of its offsets.
+template <int PER>
+__device__ __forceinline__ double thread_bounds(const BoundParams& b, const unsigned (&n)[kCounters][PER], int o0, int span,
+                                                int valid, double (&up)[PER])
+{
+    bool all = true;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        const bool in = o0 + e >= 0 && o0 + e < span && e < valid;
+        all &= !in || all_classes_present(b.m, n[0][e], n[1][e], n[2][e]);
+    }
+    const bool fast = __ballot(!all) == 0ull;          // wave-uniform
+    double pess = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < PER; ++e) {
+        up[e] = -INFINITY;
+        if (o0 + e >= 0 && o0 + e < span && e < valid) {
+            double pe;
+            if (fast) offset_bounds<true>(b, (int)n[0][e], (int)n[1][e], (int)n[2][e], up[e], pe);
+            else offset_bounds<false>(b, (int)n[0][e], (int)n[1][e], (int)n[2][e], up[e], pe);
+            pess = fmax(pess, pe);
+        }
+    }
+    return pess;
 }
 
 // ---- count kernel --------------------------------------------------------------
@@ -654,17 +699,9 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         const CountArgs::CountSelect& sel = a.sel[mode];
         __syncthreads();                              // everyone is done reading the cells / the previous mode's s_best
         double up[kPer];
-        double pess = -INFINITY;
-#pragma unroll
-        for (int e = 0; e < kPer; ++e) {
-            const int o = (int)blockIdx.x * kTileStride + o_local + e - a.lead;      // relative to the range's first offset
-            up[e] = -INFINITY;
-            if (o >= 0 && o < a.span && o_local + e < kTileStride) {
-                double pe;
-                offset_bounds(sel.bounds, (int)n[0][e], (int)n[1][e], (int)n[2][e], up[e], pe);
-                pess = fmax(pess, pe);
-            }
-        }
+        // offsets relative to the range's first one; the tile answers for its first kTileStride positions
+        const double pess = thread_bounds<kPer>(sel.bounds, n, (int)blockIdx.x * kTileStride + o_local - a.lead, a.span,
+                                                kTileStride - o_local, up);
         unsigned long long key = order_key(pess);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
@@ -871,17 +908,8 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
             int* cand = sel.cand + (size_t)q * a.cap;
             double* cand_upper = sel.cand_upper + (size_t)q * a.cap;
             double up[kDuoPer];
-            double pess = -INFINITY;
-#pragma unroll
-            for (int e = 0; e < kDuoPer; ++e) {
-                const int o = (int)blockIdx.x * kTileStride + o_local + e - a.lead;
-                up[e] = -INFINITY;
-                if (o >= 0 && o < a.span && o_local + e < kTileStride) {
-                    double pe;
-                    offset_bounds(sel.bounds, (int)n[0][e], (int)n[1][e], (int)n[2][e], up[e], pe);
-                    pess = fmax(pess, pe);
-                }
-            }
+            const double pess = thread_bounds<kDuoPer>(sel.bounds, n, (int)blockIdx.x * kTileStride + o_local - a.lead, a.span,
+                                                       kTileStride - o_local, up);
             unsigned long long key = order_key(pess);
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
