@@ -316,9 +316,13 @@ __device__ __forceinline__ void shift_planes(Counter (&cnt)[2][kCounters], unsig
 #pragma unroll
         for (int p = 0; p < (int)(sizeof(cnt[0][k].plane) / sizeof(unsigned)); ++p) {
             const unsigned a = cnt[0][k].plane[p], b = cnt[1][k].plane[p];
-            // wave_rol:1: lane l <- lane l+1 (every lane is written; `old` only spares a v_mov 0)
-            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp((int)a, (int)a, 0x134, 0xf, 0xf, false);
-            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp((int)b, (int)b, 0x134, 0xf, 0xf, false);
+            // wave_rol:1: lane l <- lane l+1.  Every lane is written, so the DPP's tied `old` operand is a value
+            // nobody computes (an empty asm names a register): no copy in front of the DPP mov, no hazard nop.
+            int ua, ub;
+            asm volatile("" : "=v"(ua));          // (volatile: two distinct registers, not one merged value)
+            asm volatile("" : "=v"(ub));
+            const unsigned ra = (unsigned)__builtin_amdgcn_update_dpp(ua, (int)a, 0x134, 0xf, 0xf, false);
+            const unsigned rb = (unsigned)__builtin_amdgcn_update_dpp(ub, (int)b, 0x134, 0xf, 0xf, false);
             cnt[0][k].plane[p] = __builtin_amdgcn_alignbit(last_lane ? rb : ra, a, s);
             cnt[1][k].plane[p] = __builtin_amdgcn_alignbit(rb, b, s);
         }
