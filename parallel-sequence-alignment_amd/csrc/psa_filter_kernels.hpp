@@ -274,15 +274,17 @@ __device__ __forceinline__ void lds_retire(SlotRegs& n)
 // l + k (word l) and l + 64 + k (word l+64) of its symbol's row: the round's base address moves
 // on by kUnroll slots per round, T is an immediate offset.  `cur` holds this char's slots; the
 // next char's are requested first (T == 31: char 0 of the next round).
-template <int T, int HOW, typename Counter>
+// BASE: byte offset of the round's first slot from lane_addr (an immediate: the second round of a pair reads
+// kUnroll slots further on without another address add).
+template <int T, int HOW, int BASE, typename Counter>
 __device__ __forceinline__ void class_step(Counter (&cnt)[2][kCounters], SlotRegs& cur,
                                            const unsigned (&rowoff)[kUnroll], unsigned next_rowoff,
                                            unsigned lane_addr)
 {
     SlotRegs nxt;
     // Seq2 symbol of the next char as a wave-uniform LDS row offset (symbol << kRowShift)
-    if constexpr (T + 1 < kUnroll) lds_issue<8 * (T + 1)>(nxt, lane_addr + rowoff[(T + 1) % kUnroll]);
-    else lds_issue<8 * kUnroll>(nxt, lane_addr + next_rowoff);
+    if constexpr (T + 1 < kUnroll) lds_issue<BASE + 8 * (T + 1)>(nxt, lane_addr + rowoff[(T + 1) % kUnroll]);
+    else lds_issue<BASE + 8 * kUnroll>(nxt, lane_addr + next_rowoff);
     const unsigned lo0 = (unsigned)cur.v[0], hi0 = (unsigned)(cur.v[0] >> 32);
     const unsigned lo1 = (unsigned)cur.v[1], hi1 = (unsigned)(cur.v[1] >> 32);
     cnt[0][0].template push<T, HOW>(lo0);
@@ -295,12 +297,12 @@ __device__ __forceinline__ void class_step(Counter (&cnt)[2][kCounters], SlotReg
     cur = nxt;
 }
 
-template <int HOW, typename Counter, int... Ts>
+template <int HOW, int BASE, typename Counter, int... Ts>
 __device__ __forceinline__ void class_round(Counter (&cnt)[2][kCounters], SlotRegs& cur,
                                             const unsigned (&rowoff)[kUnroll], unsigned next_rowoff,
                                             unsigned lane_addr, std::integer_sequence<int, Ts...>)
 {
-    (class_step<Ts, HOW>(cnt, cur, rowoff, next_rowoff, lane_addr), ...);
+    (class_step<Ts, HOW, BASE>(cnt, cur, rowoff, next_rowoff, lane_addr), ...);
 }
 
 // Counter planes moved down by `s` bit positions (C[x] <- C[x + s], 1 <= s <= 31): word w takes
@@ -357,19 +359,18 @@ __device__ __forceinline__ void count_classes(Counter (&cnt)[2][kCounters],
             sym += kUnroll;
 #pragma unroll
             for (int q = 0; q < kUnroll; ++q) rowoff_b[q] = row_of(sym[q]);   // wave-uniform
-            class_round<kHold>(cnt, cur, rowoff_a, rowoff_b[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
-            lane_addr += 8u * kUnroll;
+            class_round<kHold, 0>(cnt, cur, rowoff_a, rowoff_b[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
             sym += kUnroll;
 #pragma unroll
             for (int q = 0; q < kUnroll; ++q) rowoff_a[q] = row_of(sym[q]);
-            class_round<kJoin>(cnt, cur, rowoff_b, rowoff_a[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
-            lane_addr += 8u * kUnroll;
+            class_round<kJoin, 8 * kUnroll>(cnt, cur, rowoff_b, rowoff_a[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
+            lane_addr += 16u * kUnroll;
         }
         if (g < class_chars) {                           // a class's odd last round
             sym += kUnroll;
 #pragma unroll
             for (int q = 0; q < kUnroll; ++q) rowoff_b[q] = row_of(sym[q]);
-            class_round<kAlone>(cnt, cur, rowoff_a, rowoff_b[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
+            class_round<kAlone, 0>(cnt, cur, rowoff_a, rowoff_b[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
 #pragma unroll
             for (int q = 0; q < kUnroll; ++q) rowoff_a[q] = rowoff_b[q];
         }
