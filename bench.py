@@ -508,7 +508,9 @@ def main():
     roofline.update({
         "traffic": traffic, "kernel": kernel_name, "kernel_ms": 1e3 * kernel_s, "queries_per_launch": kernel_queries,
         "valu": dict(valu, peak_per_s=VALU_PEAK, note="peak = 1024 SIMDs x 2.4 GHz / 2 cycles per full-rate wave64 "
-                     "instruction; instructions per launch from the committed rocprofv3 PMC pass") if valu else None,
+                     "instruction; instructions per launch from the committed rocprofv3 PMC pass.  75 % of the loop is "
+                     "v_bitop3_b32, whose 8-byte encoding issues at 1.19 ns per SIMD at this occupancy (tools/ubench/ops3): "
+                     "the mix-specific ceiling is ~0.72 of this peak (DESIGN.md 4.4)") if valu else None,
         "hbm_algorithmic": {"achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "ratio_to_peak": algorithmic_gbs / HBM_PEAK_GBS,
                             "bytes_per_launch": BYTES_PER_PAIR * pairs_launch,
