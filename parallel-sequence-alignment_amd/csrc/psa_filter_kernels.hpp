@@ -1132,6 +1132,9 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
         // ---- sum the chunk in reference order (wave 0)
         if (tid < 64) {
             int k = c0;
+#ifdef PSA_PHASE_TIMING
+            int dbg_chain = 0, dbg_batches = 0, dbg_left = 0;
+#endif
             while (k < c1) {
                 const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
                 const int e = (int)((sb >> 52) & 0x7ff);
@@ -1158,6 +1161,9 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
                     if (__ballot(tie) != 0ull) walk = false;
                 }
                 if (!walk) {
+#ifdef PSA_PHASE_TIMING
+                    ++dbg_chain;
+#endif
                     // plain chain over the next <= 64 chars; lanes past the chunk hold +0.0 (exact to add)
                     const int nb = c1 - k < 64 ? c1 - k : 64;
                     s_vals[lane] = lane < nb ? s_class[s_codes[k - c0 + lane] & 7u] : 0.0;
@@ -1210,6 +1216,9 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
                         rr[j] = s_round[(unsigned)(w[j >> 3] >> (8 * (j & 7))) & 7u];
                         t += rr[j];
                     }
+#ifdef PSA_PHASE_TIMING
+                    ++dbg_batches;
+#endif
                     const long long incl = wave_scan_inclusive(t);
                     const long long q0 = S + (incl - t);          // sum before this lane's first char
                     long long q = q0;
@@ -1244,6 +1253,9 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
                 const unsigned long long mag = (unsigned long long)(S < 0 ? -S : S);
                 s = __longlong_as_double((long long)((neg ? (1ull << 63) : 0ull) | ((unsigned long long)e << 52) |
                                                      (mag & 0xfffffffffffffull)));
+#ifdef PSA_PHASE_TIMING
+                if (left) ++dbg_left;
+#endif
                 if (left) {
                     // this char moves the sum out of the binade: one true fp64 add
                     s += s_class[s_codes[k - c0] & 7u];
@@ -1251,6 +1263,13 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+#ifdef PSA_PHASE_TIMING
+            if (tid == 0 && blockIdx.x == 0 && ci == 0) {      // how the walk of the first candidate went
+                g_phase_ts[1001][0] = (unsigned long long)dbg_chain;
+                g_phase_ts[1001][1] = (unsigned long long)dbg_batches;
+                g_phase_ts[1001][2] = (unsigned long long)dbg_left;
+            }
+#endif
         }
         if (ci == (int)blockIdx.x) PSA_RPHASE(3);
         __syncthreads();            // the next chunk overwrites s_codes

@@ -43,3 +43,6 @@ ts = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)[1000]
 names = ["start -> tables + scalars", "classify (all waves)", "walk (wave 0)", "key reduce + record", "arrive + fold + tail"]
 for k, name in enumerate(names):
     print(f"rescore {name:28s} {(ts[k + 1] - ts[k]) / 100.0:7.2f} us")
+walk = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8)[1001]
+print(f"rescore walk of the first candidate: {walk[0]} chain steps (<= 64 chars each), {walk[1]} scan steps (<= 512 chars), "
+      f"{walk[2]} binade changes")
