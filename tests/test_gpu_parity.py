@@ -804,6 +804,9 @@ def test_batch_shapes_against_sequential_engine(psa):
                     cs.set_seq2(q)
                     assert key(r) == key(cs.search(first, last)), (n, m, nq, mode)
             assert [key(r) for r in one] == [key(r) for r in hi]
+            cf.set_batch_streams(2)                                   # count launches alternating between two streams
+            assert [key(r) for r in cf.search_batch(qs, first, last)] == [key(r) for r in one]
+            cf.set_batch_streams(1)
         assert cf.fallback_count() == 0
 
 
