@@ -332,11 +332,10 @@ struct Scalars {                      // small device-side state of one filter s
 };
 
 struct FilterPlan {
-    int waves = 0;        // 8 or 16 waves per workgroup
+    int waves = 0;        // waves per workgroup (16)
     int nchunks = 0;      // char chunks (grid.y)
     int class_chars = 0;  // chars of every shift class per chunk (a chunk covers 32 x class_chars chars)
     int lds_slots = 0;
-    int row_slots = 0;    // distance of two plane rows in LDS (kRowSlots for 16 waves, packed for 8)
     int lds_bytes = 0;
     int ntiles = 0;       // offset tiles (grid.x)
 };
@@ -385,7 +384,7 @@ struct psa_context {
     hipStream_t twin = nullptr;        // owned: every other count kernel of a pooled batch (kernels overlap at their edges)
     int batch_streams = 1;             // count launches of a batch on one stream (2: alternate between two, psa_set_batch_streams)
     int batch_rescore_grid = 8;        // re-score workgroups per query inside a batch (the CUs are busy counting)
-    int granted16 = 0, granted8 = 0;   // dynamic-LDS grants of the count kernels on this context's device
+    int granted16 = 0;                 // dynamic-LDS grant of the count kernel on this context's device
     bool granted_duo = false;
     bool duo = true;                   // batches: one workgroup per tile serves several queries (psa_count_duo_kernel)
     int  duo_queries = 32;             // queries per launch of it
@@ -730,13 +729,12 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
     bool found = false;
 #ifdef PSA_EXPERIMENT
     // experiment knobs (not part of the API, compiled out of the product build): force the workgroup shape / chunk count
-    static const int force_waves = std::getenv("PSA_FILTER_WAVES") ? std::atoi(std::getenv("PSA_FILTER_WAVES")) : 0;
     static const int force_chunks = std::getenv("PSA_FILTER_CHUNKS") ? std::atoi(std::getenv("PSA_FILTER_CHUNKS")) : 0;
 #else
-    constexpr int force_waves = 0, force_chunks = 0;
+    constexpr int force_chunks = 0;
 #endif
-    for (int waves : {16, 8}) {
-        if (force_waves && waves != force_waves) continue;
+    {
+        constexpr int waves = 16;
         const int wave_classes = psa::kClasses / waves;
         for (int nchunks = 1; nchunks <= kMaxChunks && nchunks <= rounds_total; ++nchunks) {
             if (force_chunks && nchunks != force_chunks) continue;
@@ -745,23 +743,18 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
             const int class_chars = rounds * psa::kUnroll;
             if (wave_classes * class_chars > psa::kMaxWaveChars) continue;
             const int slots = psa::kTile / 32 + class_chars + 1;
-            if (slots > psa::kRowSlots) continue;             // rows are at most kRowSlots slots apart in LDS
-            // 16 waves: rows 4 KiB apart (a symbol is its row offset); 8 waves: rows packed, two workgroups per CU
-            const int row_slots = waves == 16 ? psa::kRowSlots : slots;
-            int lds = psa::kMaskRows * row_slots * 8;
+            if (slots > psa::kRowSlots) continue;             // rows are kRowSlots slots apart in LDS
+            int lds = psa::kMaskRows * psa::kRowSlots * 8;    // one workgroup per CU
             if (cells > lds) lds = cells;
             if (lds > kLdsLimit) continue;
-            // the count kernel needs ~120 VGPRs: 16 waves per CU
-            int per_cu = kLdsLimit / lds;
-            if (per_cu > 16 / waves) per_cu = 16 / waves;
             const long long blocks = (long long)ntiles * nchunks;
-            const long long rounds_cu = (blocks + 256 * per_cu - 1) / (256 * per_cu);   // waves of co-resident workgroups
-            // VALU-bound: ~8 CU-cycles per char of a workgroup alone on its CU, plus staging, the class shifts and
-            // the epilogue; the chunk workgroups of a tile meet through memory (stores, L2 write-back, arrival,
-            // read-back: ~10 us)
-            const double block_cost = 8.0 * psa::kClasses * class_chars * per_cu + 0.5 * psa::kMaskRows * slots + 5000.0 +
-                                      (nchunks > 1 ? 20000.0 : 0.0);
-            const double cost = (double)rounds_cu * block_cost;     // co-resident workgroups share the CU's VALU
+            const long long rounds_cu = (blocks + 255) / 256;        // waves of co-resident workgroups
+            // Microseconds, fitted on MI355X (tools/plan_sweep.py, gpurun_out/plan_sweep_*.txt): the youngest wave of a
+            // workgroup needs ~0.17 us per char of a class, a workgroup ~8 us around its main loop, the launch ~11 us;
+            // the chunk workgroups of a tile meet through memory (write-through stores, arrival counter, the last
+            // arriver reads the others' counts).
+            const double cost = (double)rounds_cu * (0.17 * class_chars + 8.0) + 11.0 +
+                                (nchunks > 1 ? 2.3 + 1.7 * nchunks + 0.02 * (double)blocks : 0.0);
             if (!found || cost < best_cost) {
                 found = true;
                 best_cost = cost;
@@ -769,7 +762,6 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
                 best->nchunks = nchunks;
                 best->class_chars = class_chars;
                 best->lds_slots = slots;
-                best->row_slots = row_slots;
                 best->lds_bytes = lds;
                 best->ntiles = ntiles;
             }
@@ -832,8 +824,6 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.span_pad = span_pad;
     a.class_chars = p.class_chars;
     a.lds_slots = p.lds_slots;
-    a.row_slots = p.row_slots;
-    a.row_mul = (unsigned)(8 * p.row_slots) << 20;
     a.tile_arrivals = s.d_arrivals;
     a.inline_select = inline_select ? 1 : 0;
     a.nmodes = s2 ? 2 : 1;
@@ -856,23 +846,13 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     }
     const dim3 grid(p.ntiles, p.nchunks);
     // dynamic LDS above 64 KB has to be granted per kernel (and device: the flags live in the context)
-    if (p.waves == 16) {
-        if (p.lds_bytes > c->granted16) {
-            PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
-            c->granted16 = kLdsLimit;
-        }
-        hipLaunchKernelGGL(psa::psa_count_kernel<16>, grid, dim3(16 * 64), p.lds_bytes, stream, a);
-        c->last_kernel = "psa_count_kernel<16>";
-    } else {
-        if (p.lds_bytes > c->granted8) {
-            PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<8>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
-            c->granted8 = kLdsLimit;
-        }
-        hipLaunchKernelGGL(psa::psa_count_kernel<8>, grid, dim3(8 * 64), p.lds_bytes, stream, a);
-        c->last_kernel = "psa_count_kernel<8>";
+    if (p.lds_bytes > c->granted16) {
+        PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+        c->granted16 = kLdsLimit;
     }
+    hipLaunchKernelGGL(psa::psa_count_kernel<16>, grid, dim3(16 * 64), p.lds_bytes, stream, a);
+    c->last_kernel = "psa_count_kernel<16>";
     PSA_HIP(hipGetLastError());
     return PSA_OK;
 }

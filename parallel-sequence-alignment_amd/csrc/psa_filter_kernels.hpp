@@ -540,8 +540,6 @@ struct CountArgs {
     int span_pad;     // ntiles*kTile
     int class_chars;  // chars of every shift class per chunk (multiple of kUnroll); a chunk = 32 x class_chars chars
     int lds_slots;    // slots per staged row (kTile/32 + class_chars + 1)
-    int row_slots;    // distance of two rows in LDS, in slots (the 16-wave kernel uses kRowSlots)
-    unsigned row_mul; // (8 * row_slots) << 20: __umulhi(code << kRowShift, row_mul) = the row's LDS byte offset
     int* tile_arrivals;   // [ntiles], zero between searches: chunk workgroups of a tile that have published their counts
     // single-chunk searches finish here: score bounds per offset, running best pessimistic
     // bound (atomic max), candidates = offsets whose optimistic bound reaches it.  The counts do
@@ -580,10 +578,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     const int tile_o0 = a.base + blockIdx.x * kTileStride;     // absolute offset of word 0, bit 0 (multiple of 32)
     const int chunk_k0 = blockIdx.y * a.class_chars;           // first char k of every class in this chunk
     const int slot0 = (tile_o0 >> 5) + chunk_k0;               // first staged slot
-    // rows are 4 KiB apart in the 16-wave kernel (a Seq2 symbol, stored as code << 12, is its row's byte
-    // offset); smaller workgroups pack them (two workgroups per CU) and rescale the symbol on the scalar unit
-    const int row_slots = WAVES == 16 ? kRowSlots : a.row_slots;
-    auto row_of = [&](unsigned sym) -> unsigned { return WAVES == 16 ? sym : __umulhi(sym, a.row_mul); };
+    // rows are 4 KiB apart: a Seq2 symbol, stored as code << 12, is its row's byte offset.  (A packed-row variant
+    // with 8 waves and two workgroups per CU was measured slower than this kernel for every shape: removed.)
+    static_assert(WAVES == 16, "one shape: 16 waves, one workgroup per CU");
+    constexpr int row_slots = kRowSlots;
+    auto row_of = [](unsigned sym) -> unsigned { return sym; };
 
     // Build the class planes of the window [32*slot0, +kTile+32*class_chars) in LDS: row b
     // (Seq2 symbol), slot s holds {lo, hi}: bit t of lo = class(Seq1[32*(slot0+s)+t], b) in
@@ -662,20 +661,22 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     read_cells<kPer>(n, cells, kTileWords, o_local);
     if (!a.inline_select || gridDim.y > 1) {
         unsigned long long* dst = a.partial + (size_t)blockIdx.y * a.span_pad + (size_t)blockIdx.x * kTile + o_local;
+        // write-through (sc1) stores: they leave the XCD's L2 at once, so the hand-off below needs no L2 write-back
 #pragma unroll
         for (int e = 0; e < kPer; ++e)
-            __builtin_nontemporal_store((unsigned long long)n[0][e] | ((unsigned long long)n[1][e] << 21) |
-                                        ((unsigned long long)n[2][e] << 42), dst + e);
+            __hip_atomic_store(dst + e, (unsigned long long)n[0][e] | ((unsigned long long)n[1][e] << 21) |
+                                            ((unsigned long long)n[2][e] << 42), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!a.inline_select) return;
         // Several char chunks per tile: the last chunk workgroup of the tile to arrive adds the others'
         // counts to its own and goes on alone.  The chunk workgroups may sit on different XCDs (separate
-        // L2s): every wave waits for its stores, ONE thread does the agent-scope release (an L2 write-back,
-        // expensive per call) and the arrival; the counts are read back with agent-scope loads.
+        // L2s).  Producer: every byte is stored sc1, every storing wave drains its stores (vmcnt(0)), the
+        // workgroup barrier, then ONE lane's arrival (MI355X_MICROARCH.md, "Valid forms": no release fence —
+        // an L2 write-back costs ~6 us per workgroup here).  Consumer: the last arriver's agent-scope acquire,
+        // barrier, agent-scope loads.
         __shared__ int s_last_chunk;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             const int arrived = __hip_atomic_fetch_add(a.tile_arrivals + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last_chunk = arrived == (int)gridDim.y - 1;
             if (s_last_chunk) {

@@ -14,18 +14,20 @@ import psa_amd  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
+first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+last = int(sys.argv[4]) if len(sys.argv) > 4 else n - m + 1
 ctx = psa_amd.Context()
 ctx.set_weights([1.5, 2.6, 0.3, 0.2], True)
 ctx.set_seq1(psa_amd.generate_sequence(1002, n))
 ctx.set_seq2(psa_amd.generate_sequence(2002, m))
 for _ in range(3):
-    r = ctx.search(0, n - m + 1)
+    r = ctx.search(first, last)
 lib = psa_amd._lib if hasattr(psa_amd, "_lib") else psa_amd.lib
 buf = (C.c_ulonglong * (1024 * 8))()
 lib.psa_debug_phase_ts.restype = C.c_int
 assert lib.psa_debug_phase_ts(buf) == 0
 ts = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
-nt = (n - m + 1 + 4063) // 4064 + 1
+nt = 1024
 ts = ts[:nt]
 ts = ts[ts[:, 0] > 0]
 t0 = ts[:, 0].min()
