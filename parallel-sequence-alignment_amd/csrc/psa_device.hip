@@ -572,7 +572,7 @@ psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
     return PSA_OK;
 }
 
-bool plan_filter(int first, int last, int m, FilterPlan* best);
+bool plan_filter(int first, int last, int m, FilterPlan* best, int max_chunks = 1 << 30);
 
 psa_status encode_seq2(psa_context* c, SearchSlot& s, const void* d_raw, int m, hipStream_t stream)
 {
@@ -720,7 +720,7 @@ psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last,
 constexpr int kMaxChunks = 24;
 static_assert((kMaxChunks + 1) * psa::kClasses * psa::kUnroll + psa::kUnroll <= kSeq2Slack, "class-order buffer");
 
-bool plan_filter(int first, int last, int m, FilterPlan* best)
+bool plan_filter(int first, int last, int m, FilterPlan* best, int max_chunks)
 {
     const int ntiles = (last - (first & ~31) + psa::kTileStride - 1) / psa::kTileStride;
     const int cells = psa::kCellDwords * 4;              // the epilogue's count cells reuse the plane rows
@@ -736,7 +736,7 @@ bool plan_filter(int first, int last, int m, FilterPlan* best)
     {
         constexpr int waves = 16;
         const int wave_classes = psa::kClasses / waves;
-        for (int nchunks = 1; nchunks <= kMaxChunks && nchunks <= rounds_total; ++nchunks) {
+        for (int nchunks = 1; nchunks <= kMaxChunks && nchunks <= rounds_total && nchunks <= max_chunks; ++nchunks) {
             if (force_chunks && nchunks != force_chunks) continue;
             const int rounds = (rounds_total + nchunks - 1) / nchunks;
             if (nchunks > 1 && rounds * (nchunks - 1) >= rounds_total) continue;   // last chunk would be empty
@@ -870,6 +870,27 @@ bool duo_fits(int m, int* class_chars, int* lds_slots)
     return true;
 }
 
+// With fewer tiles than CUs the queries of a launch are spread over grid.y: (tile, y) workgroups of `qpb` queries each
+// (an even number: one query per wave group at a time), about one workgroup per CU.
+int duo_queries_per_workgroup(int ntiles, int count, int* yblocks)
+{
+    int want = (256 + ntiles - 1) / ntiles;                 // y blocks that fill 256 CUs
+    if (want < 1) want = 1;
+    int qpb = (count + want - 1) / want;
+    qpb = (qpb + 1) & ~1;
+    if (qpb < 2) qpb = 2;
+    *yblocks = (count + qpb - 1) / qpb;
+    return qpb;
+}
+
+// queries per launch of the batch kernel: 32 for a long Seq1 (one workgroup per tile and launch, the re-score of a launch
+// overlaps the next launch), more when there are few tiles, so that tiles x y-blocks still fills the GPU
+int duo_queries_per_launch(const psa_context* c, int ntiles)
+{
+    const int want = (256 + ntiles - 1) / ntiles;           // y blocks, two queries each
+    return std::max(c->duo_queries, std::min(4096, 2 * want));
+}
+
 psa_status launch_count_duo(psa_context* c, const unsigned* s2cls, size_t s2_stride, int m, int count, int first, int last,
                             int nmodes, const TableSet* tables, Scalars* const scal[2], int* const cand[2],
                             double* const cand_upper[2], hipStream_t stream)
@@ -906,7 +927,9 @@ psa_status launch_count_duo(psa_context* c, const unsigned* s2cls, size_t s2_str
         c->granted_duo = true;
     }
     const int ntiles = (last - base + psa::kTileStride - 1) / psa::kTileStride;
-    hipLaunchKernelGGL(psa::psa_count_duo_kernel, dim3(ntiles), dim3(1024), psa::kDuoLdsBytes, stream, a);
+    int yblocks = 0;
+    a.qpb = duo_queries_per_workgroup(ntiles, count, &yblocks);
+    hipLaunchKernelGGL(psa::psa_count_duo_kernel, dim3(ntiles, yblocks), dim3(1024), psa::kDuoLdsBytes, stream, a);
     PSA_HIP(hipGetLastError());
     return PSA_OK;
 }
@@ -1411,8 +1434,11 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
     }
     // filter searches keep all per-query state in pools (entry mode*nq + q): nothing is
     // reused inside the batch and the count kernels never wait for the re-score stream
+    // A batch spreads over the GPU by its queries (the batch kernel's grid is tiles x query blocks), so it keeps all
+    // chars of a query in one workgroup whenever they fit; char chunks are for a Seq2 too long for that.
     FilterPlan plan;
-    const bool pooled = filter && plan_filter(first, last, m, &plan);      // filter => a plan exists (use_filter)
+    bool pooled = filter && nq >= 2 && plan_filter(first, last, m, &plan, 1);
+    if (!pooled) pooled = filter && plan_filter(first, last, m, &plan);      // filter => a plan exists (use_filter)
     static_assert(sizeof(Scalars) % sizeof(unsigned long long) == 0, "the encode kernel zeroes the pool in 8-byte words");
     int zero_words = 0;
     if (pooled) {
@@ -1467,8 +1493,9 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
         // several queries per count launch (two wave groups per tile share the planes and alternate between
         // main loop and epilogue); launches alternate between the two streams, the re-scores follow on the third
         int launch = 0;
-        for (int q0 = 0; q0 < nq; q0 += c->duo_queries, ++launch) {
-            const int count = std::min(c->duo_queries, nq - q0);
+        const int per_launch = duo_queries_per_launch(c, plan.ntiles);
+        for (int q0 = 0; q0 < nq; q0 += per_launch, ++launch) {
+            const int count = std::min(per_launch, nq - q0);
             hipStream_t front = twin && (launch & 1) ? c->twin : c->stream;
             Scalars* scal[2];
             int* cand[2];

@@ -769,6 +769,9 @@ struct DuoArgs {
     int class_chars;      // chars per shift class (multiple of kUnroll); a wave walks 4 classes (<= kDuoMaxWaveChars chars)
     int lds_slots;        // slots per staged row
     int nq;               // queries of this launch
+    int qpb;              // queries per workgroup: workgroup (tile, y) serves queries [y * qpb, (y + 1) * qpb) of the launch.
+                          // Long Seq1: one workgroup per tile serves the whole launch; few tiles: the queries are spread
+                          // over grid.y so that the launch still fills the GPU
     int nmodes;
     int cap;
     int first, lead, span;
@@ -853,7 +856,9 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
                                                         group * kDuoScratchBytes);
     unsigned* const bar = &s_bar[group];
     unsigned bar_target = 0u;
-    if (group == 1 && a.nq > 1) {
+    const int q_begin = (int)blockIdx.y * a.qpb;
+    const int q_end = q_begin + a.qpb < a.nq ? q_begin + a.qpb : a.nq;
+    if (group == 1 && q_end - q_begin > 2) {
         const unsigned long long t0 = wall_clock64();
         while (wall_clock64() - t0 < a.skew_ticks) __builtin_amdgcn_s_sleep(8);
     }
@@ -865,7 +870,7 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
 #else
 #define PSA_DPHASE(k) do { } while (0)
 #endif
-    for (int q = group; q < a.nq; q += 2) {
+    for (int q = q_begin + group; q < q_end; q += 2) {
         PSA_DPHASE(0);
         // younger waves of the group first: the hardware favours the oldest wave, which would finish its share
         // long before the others and wait for them at the first epilogue barrier

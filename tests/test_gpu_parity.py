@@ -525,6 +525,34 @@ def test_bench_n_rank_paths_rehearsed_on_one_gpu(psa, extra):
         assert line["config"]["queries_per_step"] == (32 if extra[1] == "weak" else 16)
 
 
+@pytest.mark.parametrize("n,m,nq", [(9711, 2131, 37), (10000, 5000, 8), (30000, 700, 101), (4100, 33, 257)])
+def test_batches_of_reference_sized_inputs_spread_over_query_blocks(psa, oracle, n, m, nq):
+    """Few offset tiles (the reference's own sizes: |Seq1| <= 10,000): the batch kernel's grid is tiles x query
+    blocks so that the batch still fills the GPU (odd query counts, one to three tiles, a last block of one query).
+    Every result equals a single search; a sample is checked against the oracle; MIN+MAX from the same pass."""
+    s1 = psa.generate_sequence(900 + n, n)
+    qs = [psa.generate_sequence(7000 + q, m) for q in range(nq)]
+    qs[nq // 2] = s1[100:100 + m]                                  # an exact copy somewhere
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    with psa.Context(0) as c:
+        c.set_engine(psa.ENGINE_FILTER)
+        c.set_weights(W_README, True)
+        c.set_seq1(s1)
+        got = c.search_batch(qs)
+        hi, lo = c.search_batch_minmax(qs)
+        assert [key(r) for r in hi] == [key(r) for r in got]
+        for q in range(0, nq, max(1, nq // 9)):
+            c.set_weights(W_README, True)
+            c.set_seq2(qs[q])
+            assert key(c.search()) == key(got[q]), q
+            c.set_weights(W_README, False)
+            assert key(c.search()) == key(lo[q]), q
+        for q in (0, nq // 2, nq - 1):
+            assert_same(got[q], oracle.search(s1, qs[q], W_README, True, threads=8))
+            assert_same(lo[q], oracle.search(s1, qs[q], W_README, False, threads=8))
+        assert [r.shard for r in got] == list(range(nq))
+
+
 def test_filter_engine_synthetic_golden_and_ranges(psa, oracle):
     gold = json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))
     with psa.Context(0) as c:
