@@ -1345,6 +1345,8 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
 {
     if (!c || !out) { set_last_error("psa_search_wait: NULL argument"); return PSA_ERR_ARG; }
     if (!c->pending) { set_last_error("psa_search_wait: no search in flight"); return PSA_ERR_STATE; }
+    PSA_TRY(ensure_device(c));                // (a group waits for several devices' searches in turn; the retry
+                                              // paths below launch kernels)
     PSA_HIP(hipStreamSynchronize(c->stream));
     c->pending = false;
     c->slot[0].scal_dirty = false;            // the search ran to its end: scalars are zero again
@@ -1929,8 +1931,8 @@ psa_status psa_group_create(const int* devices, int ndev, psa_group** out)
             PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_send[i]), sizeof(psa_result)));
             PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_recv[i]), sizeof(psa_result) * (size_t)ndev));
         }
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_send), sizeof(psa_result) * (size_t)ndev, hipHostMallocDefault));
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_recv), sizeof(psa_result) * (size_t)ndev * ndev, hipHostMallocDefault));
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_send), sizeof(psa_result) * (size_t)ndev, hipHostMallocPortable));
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_recv), sizeof(psa_result) * (size_t)ndev * ndev, hipHostMallocPortable));
         return PSA_OK;
     }();
     if (st != PSA_OK) { psa_group_destroy(g); return st; }
