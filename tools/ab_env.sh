@@ -1,5 +1,7 @@
 #!/bin/bash
-# A/B of env settings on the current library in one gpurun call: tools/ab_env.sh "A=1,B=2" "A=0" ...
+# A/B of experiment-knob settings in one gpurun call: tools/ab_env.sh "A=1,B=2" "A=0" ...
+# (the knobs exist only in the debug library, which this script selects)
+export PSA_AMD_LIB=${PSA_AMD_LIB:-$GRAFT_REPO_ROOT/parallel-sequence-alignment_amd/psa_amd/libpsa_debug.so}
 for rep in 1 2 3; do
 for spec in "$@"; do
   envs=$(echo "$spec" | tr ',' ' ')
