@@ -196,6 +196,13 @@ psa_status psa_group_set_seq2(psa_group* g, const char* seq2, int m);
 psa_status psa_search_sharded(psa_group* g, int first_offset, int last_offset, psa_result* out,
                               psa_result* shard_records);
 
+/* A batch of queries over the group (BASELINE.json configs[4] on several GPUs): nq queries of m characters, `stride`
+ * bytes apart in host memory, dealt to the devices in contiguous blocks, each block through psa_search_batch (or
+ * psa_search_batch_minmax when results_min != NULL: results = MAX, results_min = MIN) on its device, ONE RCCL
+ * all-gather of the records.  Needs psa_group_set_weights and psa_group_set_seq1. */
+psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, int m, size_t stride,
+                                    int first_offset, int last_offset, psa_result* results, psa_result* results_min);
+
 /* Fold of per-shard records with the reference's merge order
  * (is_swapable, cuda_funcs.cu:290-307: strictly better score, then lower
  * offset, then lower char_offset).  Host-only, no device needed. */

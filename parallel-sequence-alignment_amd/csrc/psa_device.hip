@@ -21,6 +21,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "psa_internal.hpp"
@@ -1896,6 +1897,11 @@ struct psa_group {
     std::vector<psa_result*>  d_recv;     // per device: all ndev records after the exchange
     psa_result*               h_send = nullptr;   // pinned [ndev]
     psa_result*               h_recv = nullptr;   // pinned [ndev][ndev]
+    // batches: per device a block of `per` records per mode in, all ndev blocks out
+    std::vector<psa_result*>  d_bsend, d_brecv;
+    psa_result*               h_bsend = nullptr;  // pinned [ndev][2 * per]
+    psa_result*               h_brecv = nullptr;  // pinned [ndev][2 * per] (device 0's copy of the gathered records)
+    int                       batch_per = 0;
     int is_max = 1;
     bool have_weights = false;
     int n = -1, m = -1;
@@ -1950,8 +1956,15 @@ void psa_group_destroy(psa_group* g)
         (void)hipFree(g->d_send[i]);
         (void)hipFree(g->d_recv[i]);
     }
+    for (size_t i = 0; i < g->d_bsend.size(); ++i) {
+        (void)hipSetDevice(g->devices[i]);
+        (void)hipFree(g->d_bsend[i]);
+        (void)hipFree(g->d_brecv[i]);
+    }
     if (g->h_send) (void)hipHostFree(g->h_send);
     if (g->h_recv) (void)hipHostFree(g->h_recv);
+    if (g->h_bsend) (void)hipHostFree(g->h_bsend);
+    if (g->h_brecv) (void)hipHostFree(g->h_brecv);
     for (psa_context* c : g->ctx) psa_destroy(c);
     delete g;
 }
@@ -2048,6 +2061,104 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
     return psa_fold(g->h_recv, ndev, g->is_max, out);
 }
 
+
+// A batch of queries over the group (BASELINE.json configs[4] on several GPUs): the queries are dealt to the devices
+// in contiguous blocks (the last device takes the remainder, as cpu_funcs.c:128-133 deals offsets), every device runs
+// its block through psa_search_batch / _minmax on its own host thread (the calls block), then ONE RCCL all-gather
+// leaves all records on every device and the host copies device 0's set.  results_min == NULL: one mode (the group's).
+psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, int m, size_t stride,
+                                    int first, int last, psa_result* results, psa_result* results_min)
+{
+    if (!g || !queries || !results || nq < 1 || stride < (size_t)m) {
+        set_last_error("psa_search_batch_sharded: bad arguments");
+        return PSA_ERR_ARG;
+    }
+    if (!g->have_weights || g->n < 0) { set_last_error("weights and seq1 must be set before a search"); return PSA_ERR_STATE; }
+    const int ndev = (int)g->ctx.size();
+    const int nmodes = results_min ? 2 : 1;
+    const int per = (nq + ndev - 1) / ndev;                 // records per device and mode in the exchange (padded)
+    if (per > g->batch_per) {
+        for (size_t i = 0; i < g->d_bsend.size(); ++i) {
+            PSA_HIP(hipSetDevice(g->devices[i]));
+            (void)hipFree(g->d_bsend[i]);
+            (void)hipFree(g->d_brecv[i]);
+        }
+        if (g->h_bsend) (void)hipHostFree(g->h_bsend);
+        if (g->h_brecv) (void)hipHostFree(g->h_brecv);
+        g->h_bsend = g->h_brecv = nullptr;
+        g->d_bsend.assign((size_t)ndev, nullptr);
+        g->d_brecv.assign((size_t)ndev, nullptr);
+        g->batch_per = 0;
+        for (int i = 0; i < ndev; ++i) {
+            PSA_HIP(hipSetDevice(g->devices[i]));
+            PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_bsend[i]), sizeof(psa_result) * 2 * (size_t)per));
+            PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_brecv[i]), sizeof(psa_result) * 2 * (size_t)per * ndev));
+        }
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_bsend), sizeof(psa_result) * 2 * (size_t)per * ndev, hipHostMallocPortable));
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_brecv), sizeof(psa_result) * 2 * (size_t)per * ndev, hipHostMallocPortable));
+        g->batch_per = per;
+    }
+    // the devices' blocks: device i searches queries [lo_i, hi_i)
+    const int base = nq / ndev;
+    std::vector<int> lo((size_t)ndev), hi((size_t)ndev);
+    std::vector<psa_status> status((size_t)ndev, PSA_OK);
+    std::vector<std::string> errors((size_t)ndev);
+    std::vector<std::thread> workers;
+    psa_result none;
+    none.score = 0.0; none.offset = -1; none.char_offset = -1; none.ch = 0; none.shard = -1; none.pairs = 0;
+    for (int i = 0; i < ndev; ++i) {
+        lo[i] = base * i;
+        hi[i] = i == ndev - 1 ? nq : lo[i] + base;
+        psa_result* mine = g->h_bsend + (size_t)i * 2 * per;          // [mode][per]
+        for (int k = 0; k < 2 * per; ++k) mine[k] = none;
+        if (hi[i] <= lo[i]) continue;
+        workers.emplace_back([=, &status, &errors]() {
+            const char* q0 = queries + (size_t)lo[i] * stride;
+            const int count = hi[i] - lo[i];
+            psa_status st;
+            if (nmodes == 2) {
+                // the group's mode first: results / results_min are MAX / MIN
+                psa_result* mx = mine;
+                psa_result* mn = mine + per;
+                st = psa_search_batch_minmax(g->ctx[i], q0, count, m, stride, first, last, mx, mn);
+            } else {
+                st = psa_search_batch(g->ctx[i], q0, count, m, stride, first, last, mine);
+            }
+            status[i] = st;
+            if (st != PSA_OK) errors[i] = psa_last_error();             // (thread-local in the worker)
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (int i = 0; i < ndev; ++i)
+        if (status[i] != PSA_OK) { set_last_error(errors[i]); return status[i]; }
+    // the exchange: one all-gather of the per-device blocks
+    const size_t block = sizeof(psa_result) * 2 * (size_t)per;
+    for (int i = 0; i < ndev; ++i) {
+        PSA_HIP(hipSetDevice(g->devices[i]));
+        PSA_HIP(hipMemcpyAsync(g->d_bsend[i], g->h_bsend + (size_t)i * 2 * per, block, hipMemcpyHostToDevice, g->ctx[i]->stream));
+    }
+    PSA_NCCL(g_rccl.group_start());
+    for (int i = 0; i < ndev; ++i)
+        PSA_NCCL(g_rccl.all_gather(g->d_bsend[i], g->d_brecv[i], block, ncclChar, g->comm[i], g->ctx[i]->stream));
+    PSA_NCCL(g_rccl.group_end());
+    PSA_HIP(hipSetDevice(g->devices[0]));
+    PSA_HIP(hipMemcpyAsync(g->h_brecv, g->d_brecv[0], block * (size_t)ndev, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+    for (int i = 0; i < ndev; ++i) {
+        PSA_HIP(hipSetDevice(g->devices[i]));
+        PSA_HIP(hipStreamSynchronize(g->ctx[i]->stream));
+    }
+    for (int i = 0; i < ndev; ++i)
+        for (int q = lo[i]; q < hi[i]; ++q) {
+            const psa_result* blockp = g->h_brecv + (size_t)i * 2 * per;
+            results[q] = blockp[q - lo[i]];
+            results[q].shard = q;
+            if (results_min) {
+                results_min[q] = blockp[per + (q - lo[i])];
+                results_min[q].shard = q;
+            }
+        }
+    return PSA_OK;
+}
 }  // extern "C"
 
 extern "C" {

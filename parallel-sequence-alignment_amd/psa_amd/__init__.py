@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "psa_search_batch_minmax", "psa_search_batch_minmax_device",
     "psa_debug_counts", "psa_fallback_count", "psa_reselect_count", "psa_duo_retry_count", "psa_debug_rescore",
     "psa_group_create", "psa_group_destroy", "psa_group_size", "psa_group_set_weights",
-    "psa_group_set_seq1", "psa_group_set_seq2", "psa_search_sharded",
+    "psa_group_set_seq1", "psa_group_set_seq2", "psa_search_sharded", "psa_search_batch_sharded",
     "psa_fold", "psa_shard_range", "psa_build_tables",
     "psa_set_profiling", "psa_last_timing", "psa_profile_totals", "psa_last_kernel_queries",
     "psa_generate_sequence", "psa_last_error", "psa_version",
@@ -102,6 +102,7 @@ def _load() -> C.CDLL:
     lib.psa_group_set_seq1.argtypes = [vp, C.c_char_p, i]
     lib.psa_group_set_seq2.argtypes = [vp, C.c_char_p, i]
     lib.psa_search_sharded.argtypes = [vp, i, i, C.POINTER(Result), C.POINTER(Result)]
+    lib.psa_search_batch_sharded.argtypes = [vp, C.c_char_p, i, i, C.c_size_t, i, i, C.POINTER(Result), C.POINTER(Result)]
     lib.psa_fold.argtypes = [C.POINTER(Result), i, i, C.POINTER(Result)]
     lib.psa_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.psa_shard_range.restype = None
@@ -388,6 +389,20 @@ class Group:
     def set_seq2(self, seq2: bytes):
         _check(lib.psa_group_set_seq2(self._h, seq2, len(seq2)))
         self.m = len(seq2)
+
+    def search_batch(self, queries: Sequence[bytes], minmax: bool = False,
+                     first: Optional[int] = None, last: Optional[int] = None):
+        """Equal-length host queries dealt to the group's devices -> list of Result (or (MAX, MIN) lists)."""
+        m = len(queries[0])
+        if any(len(q) != m for q in queries):
+            raise ValueError("all queries of a batch must have the same length")
+        first = 0 if first is None else first
+        last = self.n - m + 1 if last is None else last
+        hi = (Result * len(queries))()
+        lo = (Result * len(queries))()
+        _check(lib.psa_search_batch_sharded(self._h, b"".join(queries), len(queries), m, m, first, last, hi,
+                                            lo if minmax else None))
+        return (list(hi), list(lo)) if minmax else list(hi)
 
     def search(self, first: Optional[int] = None, last: Optional[int] = None):
         """-> (folded Result, [per-device Result])"""

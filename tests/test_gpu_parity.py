@@ -464,6 +464,20 @@ def test_sharded_search_through_the_c_abi(psa, oracle, reference_records):
         assert (res.offset, res.char_offset, chr(res.ch), res.score) == (4505, 144, "E", -4879.0)
         with pytest.raises(psa.PsaError):
             g.search(5, 5)
+        # a batch over the group (configs[4] behind the C ABI): queries dealt to the devices, one exchange
+        qs = [psa.generate_sequence(3100 + q, 700) for q in range(7)]
+        qs[3] = s10[1234:1934]
+        got = g.search_batch(qs)
+        hi, lo = g.search_batch(qs, minmax=True)
+        with psa.Context(0) as c:
+            c.set_weights(w0, max0)
+            c.set_seq1(s10)
+            want = c.search_batch(qs)
+            want_hi, want_lo = c.search_batch_minmax(qs)
+        key = lambda r: (r.score, r.offset, r.char_offset, r.ch, r.shard, r.pairs)
+        assert [key(r) for r in got] == [key(r) for r in want]
+        assert [key(r) for r in hi] == [key(r) for r in want_hi] and [key(r) for r in lo] == [key(r) for r in want_lo]
+        assert_same(lo[3], oracle.search(s10, qs[3], w0, False, threads=4))
     with pytest.raises(psa.PsaError):
         psa.Group([0, 0])                                     # a device listed twice
 
