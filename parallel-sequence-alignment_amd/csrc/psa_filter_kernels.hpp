@@ -563,7 +563,7 @@ struct CountArgs {
 #ifdef PSA_PHASE_TIMING
 // debug build only: 100 MHz timestamps of the count kernel's phases, [block][phase]
 __device__ unsigned long long g_phase_ts[1024][8];
-#define PSA_PHASE(k) do { if (tid == 0 && blockIdx.x < 1024) g_phase_ts[blockIdx.x][k] = wall_clock64(); } while (0)
+#define PSA_PHASE(k) do { if (tid == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1000) g_phase_ts[blockIdx.y * gridDim.x + blockIdx.x][k] = wall_clock64(); } while (0)
 #else
 #define PSA_PHASE(k) do { } while (0)
 #endif
