@@ -74,188 +74,194 @@ static double g_pair[32 * 32];
 
 static int symbol_index(char c) { return c == PSA_HYPHEN ? 26 : (c >= 'A' && c <= 'Z' ? c - 'A' : -1); }
 
-/* ---- the CPU share of a hybrid run (cpu_funcs.c:222-300), table-driven ----
- * Everything find_best_mutant_offset evaluates per pair depends on (c1, c2, weights, mode) only; the library's
- * host-side table builder (psa_build_tables: the reference's get_hashtable_sign / get_weight / get_substitute
- * rules) gives the pair score P, the substitute SUB and its delta, and this scorer adds them in the reference's
- * order.  It is the reference-side role of cpu_funcs.c in this program, not a fallback of the library. */
+/* ---- the CPU share of a hybrid run, table-driven ---------------------------------------------
+ * What the reference's host threads compute for their offsets (find_best_mutant_cpu / find_best_mutant_offset,
+ * cpu_funcs.c:222-300) depends per pair on (c1, c2, weights, mode) only.  The library's host-side table builder
+ * (psa_build_tables: the reference's sign, weight and substitution rules) gives the pair score, the substitute and
+ * its delta per symbol pair; both sequences are turned into table indices once, and an offset is one pass over
+ * `row[i] + col[o + i]`.  The pair scores are added one by one in index order (the order decides how near-tied
+ * offsets resolve, cpu_funcs.c:278); a substitution replaces the running choice only when its delta is strictly
+ * better (cpu_funcs.c:287-294: the first position wins).  This is the role cpu_funcs.c plays in the reference's
+ * program; it lives in this program only — libpsa_amd.so has no CPU search. */
 #define PSA_THREADS_COUNT 4            /* THREADS_COUNT, def.h:18 */
-static double        g_P[32 * 32], g_DELTA[32 * 32];
-static unsigned char g_SUB[32 * 32];
 
-/* is_swapable, cuda_funcs.cu:290-307 */
-static int is_swapable(const Mutant* m1, const Mutant* m2, double score1, double score2, int is_max)
+typedef struct {
+    double score;          /* total + best delta; -INF / +INF when nothing could be substituted */
+    int    offset, char_offset;
+    char   ch;
+} Candidate;
+
+static double        g_score_of[32 * 32], g_delta_of[32 * 32];
+static unsigned char g_sub_of[32 * 32];
+static int*          g_col;            /* 32 * symbol of seq1[j] */
+static int*          g_row;            /* symbol of seq2[i] */
+
+static Candidate no_candidate(int is_max)
 {
-    if ((is_max && score2 > score1) || (!is_max && score2 < score1)) return 1;
-    if (score2 == score1) {
-        if (m2->offset < m1->offset) return 1;
-        if (m2->offset == m1->offset && m2->char_offset < m1->char_offset) return 1;
-    }
-    return 0;
+    Candidate c = {is_max ? -INFINITY : INFINITY, -1, -1, PSA_NO_CHAR};
+    return c;
 }
 
-/* find_best_mutant_offset, cpu_funcs.c:257-300 */
-static double cpu_best_mutant_offset(const ProgramData* data, int iterations, int offset, Mutant* mt)
+/* the reference's total order of results (cuda_funcs.cu:290-307): better score, then lower offset, then lower position */
+static int candidate_beats(const Candidate* challenger, const Candidate* holder, int is_max)
 {
-    double total_score = 0;
-    double best_mutant_diff = data->is_max ? -INFINITY : INFINITY;
+    if (challenger->score != holder->score) return is_max ? challenger->score > holder->score : challenger->score < holder->score;
+    if (challenger->offset != holder->offset) return challenger->offset < holder->offset;
+    return challenger->char_offset < holder->char_offset;
+}
+
+static Candidate score_one_offset(int is_max, int chars, int offset)
+{
+    const int* col = g_col + offset;
+    Candidate c = no_candidate(is_max);
+    double sum = 0.0, best_delta = c.score;
     int i;
-    mt->offset = -1;
-    mt->char_offset = -1;
-    mt->ch = PSA_NO_CHAR;
-    for (i = 0; i < iterations; i++) {
-        const int k = symbol_index(data->seq1[offset + i]) * 32 + symbol_index(data->seq2[i]);
-        const double pair_score = g_P[k];
-        total_score += pair_score;                     /* sequential fp64 sum: the order is part of the contract */
-        if (g_SUB[k] == 0) continue;
-        if ((data->is_max && g_DELTA[k] > best_mutant_diff) || (!data->is_max && g_DELTA[k] < best_mutant_diff)) {
-            best_mutant_diff = g_DELTA[k];
-            mt->ch = (char)g_SUB[k];
-            mt->char_offset = i;
-            mt->offset = offset;
+    for (i = 0; i < chars; ++i) {
+        const int pair = col[i] + g_row[i];
+        sum += g_score_of[pair];
+        if (g_sub_of[pair] && (is_max ? g_delta_of[pair] > best_delta : g_delta_of[pair] < best_delta)) {
+            best_delta = g_delta_of[pair];
+            c.char_offset = i;
+            c.ch = (char)g_sub_of[pair];
         }
     }
-    if (mt->ch == PSA_NO_CHAR) return best_mutant_diff;
-    return total_score + best_mutant_diff;
+    if (c.ch != PSA_NO_CHAR) {
+        c.offset = offset;
+        c.score = sum + best_delta;
+    }
+    return c;
 }
 
-/* find_best_mutant_cpu, cpu_funcs.c:222-253 (one thread's slice; the caller merges under a critical section) */
-static double cpu_best_mutant_range(const ProgramData* data, int iterations, int first_offset, int last_offset, Mutant* best)
+static Candidate best_of_offsets(int is_max, int chars, int from, int to)
 {
-    double best_score = data->is_max ? -INFINITY : INFINITY;
-    Mutant best_mutant = {-1, -1, PSA_NO_CHAR}, tmp;
+    Candidate best = no_candidate(is_max);
     int o;
-    for (o = first_offset; o < last_offset; o++) {
-        const double score = cpu_best_mutant_offset(data, iterations, o, &tmp);
-        if (is_swapable(&best_mutant, &tmp, best_score, score, data->is_max)) {
-            best_mutant = tmp;
-            best_mutant.offset = o;
-            best_score = score;
-        }
+    for (o = from; o < to; ++o) {
+        Candidate c = score_one_offset(is_max, chars, o);
+        if (c.offset < 0) c.offset = o;                 /* (never for sequences over [A-Z-]) */
+        if (candidate_beats(&c, &best, is_max) || best.offset < 0) best = c;
     }
-    *best = best_mutant;
-    return best_score;
+    return best;
 }
 
-/* divide_execute_tasks for one process, cpu_funcs.c:123-218 */
-static double divide_execute_tasks(const ProgramData* data, int cuda_percentage, int threads, Mutant* mt)
+static void index_sequences(const ProgramData* data)
 {
-    const int total_chars = (int)strlen(data->seq2);
-    const int total_offsets = (int)strlen(data->seq1) - total_chars + 1;
-    const int gpu_tasks = (int)((long long)total_offsets * cuda_percentage / 100);
-    const int gpu_first = 0, gpu_last = gpu_tasks;
-    const int cpu_tasks = total_offsets - gpu_tasks;
-    const int cpu_first = gpu_last, cpu_last = cpu_first + cpu_tasks;
-    double gpu_best_score = data->is_max ? -INFINITY : INFINITY;
-    double cpu_best_score = data->is_max ? -INFINITY : INFINITY;
-    Mutant gpu_mutant = {-1, -1, PSA_NO_CHAR}, cpu_mutant = {-1, -1, PSA_NO_CHAR};
-
-    if (cpu_tasks > 0) {
-        size_t i;
-        if (psa_build_tables(data->weights, data->is_max, g_P, g_SUB, g_DELTA, NULL) != PSA_OK) {
-            fprintf(stderr, "Failed to build the score tables - %s\n", psa_last_error());
-            exit(EXIT_FAILURE);
-        }
-        for (i = 0; data->seq1[i]; ++i)
-            if (symbol_index(data->seq1[i]) < 0) { fprintf(stderr, "seq1 contains a character outside [A-Z-]\n"); exit(EXIT_FAILURE); }
-        for (i = 0; data->seq2[i]; ++i)
-            if (symbol_index(data->seq2[i]) < 0) { fprintf(stderr, "seq2 contains a character outside [A-Z-]\n"); exit(EXIT_FAILURE); }
+    const size_t n = strlen(data->seq1), m = strlen(data->seq2);
+    size_t k;
+    if (psa_build_tables(data->weights, data->is_max, g_score_of, g_sub_of, g_delta_of, NULL) != PSA_OK) {
+        fprintf(stderr, "Failed to build the score tables - %s\n", psa_last_error());
+        exit(EXIT_FAILURE);
     }
-    if (gpu_tasks > 0 && cpu_tasks == 0) threads = 1;          /* nothing for the other threads to do */
-    if (cpu_tasks > 0 && gpu_tasks > 0 && threads < 2) threads = 2;
+    free(g_col);
+    free(g_row);
+    g_col = (int*)malloc(sizeof(int) * (n + 1));
+    g_row = (int*)malloc(sizeof(int) * (m + 1));
+    if (!g_col || !g_row) { fprintf(stderr, "out of memory\n"); exit(EXIT_FAILURE); }
+    for (k = 0; k < n; ++k) {
+        const int sym = symbol_index(data->seq1[k]);
+        if (sym < 0) { fprintf(stderr, "seq1 contains a character outside [A-Z-]\n"); exit(EXIT_FAILURE); }
+        g_col[k] = 32 * sym;
+    }
+    for (k = 0; k < m; ++k) {
+        const int sym = symbol_index(data->seq2[k]);
+        if (sym < 0) { fprintf(stderr, "seq2 contains a character outside [A-Z-]\n"); exit(EXIT_FAILURE); }
+        g_row[k] = sym;
+    }
+}
+
+/* The reference's split of one process's offsets (divide_execute_tasks, cpu_funcs.c:123-218): the first
+ * `cuda_percentage` percent go to the GPU (thread 0 blocks in gpu_run_program), the rest to the other threads, and
+ * the GPU's result stands unless the CPU's is strictly better (cpu_funcs.c:207-214; CPU offsets are the higher
+ * ones, so this is also the lowest-offset rule on ties). */
+static double run_split(const ProgramData* data, int cuda_percentage, int threads, Mutant* winner)
+{
+    const int chars = (int)strlen(data->seq2);
+    const int offsets = (int)strlen(data->seq1) - chars + 1;
+    const int on_gpu = (int)((long long)offsets * cuda_percentage / 100);
+    const int on_cpu = offsets - on_gpu;
+    const int is_max = data->is_max;
+    Candidate gpu = no_candidate(is_max), cpu = no_candidate(is_max);
+    Mutant gpu_mutant = {-1, -1, PSA_NO_CHAR};
+
+    if (on_cpu > 0) index_sequences(data);
+    if (on_cpu == 0) threads = 1;                                  /* only the GPU's driver thread has work */
+    else if (on_gpu > 0 && threads < 2) threads = 2;               /* one drives the GPU, at least one scores */
 
 #pragma omp parallel num_threads(threads)
     {
-        int num_threads = omp_get_num_threads();
-        int tid = omp_get_thread_num();
-        if (gpu_tasks > 0 && tid == 0) gpu_best_score = gpu_run_program(data, &gpu_mutant, gpu_first, gpu_last);
-        if (cpu_tasks > 0) {
-            if (gpu_tasks > 0) {        /* thread 0 waits for the GPU: the others share the CPU slice (cpu_funcs.c:185-189) */
-                num_threads -= 1;
-                tid--;
-            }
-            if (tid != -1) {
-                const int per_thread = (cpu_last - cpu_first) / num_threads;
-                const int start = cpu_first + per_thread * tid;
-                int end = start + per_thread;
-                Mutant mine;
-                double score;
-                if (tid == num_threads - 1) end = cpu_last;             /* the last thread takes the remainder */
-                score = cpu_best_mutant_range(data, total_chars, start, end, &mine);
+        const int team = omp_get_num_threads();
+        const int me = omp_get_thread_num();
+        const int scorers = on_gpu > 0 ? team - 1 : team;          /* thread 0 waits for the GPU (cpu_funcs.c:185-189) */
+        const int slot = on_gpu > 0 ? me - 1 : me;
+        if (on_gpu > 0 && me == 0) {
+            gpu.score = gpu_run_program(data, &gpu_mutant, 0, on_gpu);
+        } else if (on_cpu > 0 && slot >= 0 && slot < scorers) {
+            const int from = on_gpu + (int)((long long)on_cpu * slot / scorers);
+            const int to = on_gpu + (int)((long long)on_cpu * (slot + 1) / scorers);
+            const Candidate mine = best_of_offsets(is_max, chars, from, to);
 #pragma omp critical
-                {
-                    if (is_swapable(&cpu_mutant, &mine, cpu_best_score, score, data->is_max)) {
-                        cpu_best_score = score;
-                        cpu_mutant = mine;
-                    }
-                }
-            }
+            if (mine.offset >= 0 && (cpu.offset < 0 || candidate_beats(&mine, &cpu, is_max))) cpu = mine;
         }
     }
-    /* the GPU result, unless the CPU found a strictly better one (cpu_funcs.c:207-214) */
-    *mt = gpu_mutant;
-    if (gpu_tasks == 0 || (data->is_max && cpu_best_score > gpu_best_score) || (!data->is_max && cpu_best_score < gpu_best_score)) {
-        *mt = cpu_mutant;
-        return cpu_best_score;
+    if (on_gpu > 0 && !(on_cpu > 0 && (is_max ? cpu.score > gpu.score : cpu.score < gpu.score))) {
+        *winner = gpu_mutant;
+        return gpu.score;
     }
-    return gpu_best_score;
+    winner->offset = cpu.ch != PSA_NO_CHAR ? cpu.offset : -1;
+    winner->char_offset = cpu.char_offset;
+    winner->ch = cpu.ch;
+    return cpu.score;
 }
 
-/* score and sign string of seq2 under seq1 at `offset` (get_score_and_signs, cpu_funcs.c:430-443) */
-static double score_and_signs(const char* seq1, const char* seq2, int offset, char* signs)
+/* ---- the verification view: what the reference prints under DEBUG_PRINT (cpu_funcs.c:382-461) ------------------
+ * Five lines under each other — the signs of Seq2 against Seq1 at the winning offset, Seq2, Seq1, the mutated Seq2,
+ * its signs — every line but Seq1 indented by the offset, the mutated position in red.  The two scores come from a
+ * scorer of their own (pair table from psa_build_tables, plain sum), independent of the search. */
+static double signs_and_score(const char* seq1, const char* seq2, int offset, char* signs)
 {
+    const char* under = seq1 + offset;
     double score = 0.0;
-    size_t i;
-    for (i = 0; seq2[i] != '\0'; ++i) {
-        const int a = symbol_index(seq1[offset + i]), b = symbol_index(seq2[i]);
-        if (a < 0 || b < 0) { signs[i] = '?'; continue; }
-        signs[i] = g_sign[a * 32 + b];
-        score += g_pair[a * 32 + b];
+    size_t i = 0;
+    for (; seq2[i]; ++i) {
+        const int a = symbol_index(under[i]), b = symbol_index(seq2[i]);
+        signs[i] = a < 0 || b < 0 ? '?' : g_sign[a * 32 + b];
+        if (a >= 0 && b >= 0) score += g_pair[a * 32 + b];
     }
     signs[i] = '\0';
     return score;
 }
 
-/* the string shifted right by `offset`, the char at char_offset in red (print_with_offset, cpu_funcs.c:446-461) */
-static void print_with_offset(const char* chrs, int offset, int char_offset)
+static void aligned_row(const char* text, int indent, int red)
 {
-    const size_t len = strlen(chrs);
-    size_t i;
-    if (char_offset < 0) char_offset = 0;
-    for (i = 0; i < (size_t)offset; ++i) putchar(' ');
-    for (i = 0; i < (size_t)char_offset && i < len; ++i) putchar(chrs[i]);
-    if ((size_t)char_offset < len) printf("\033[0;31m%c\033[0m", chrs[char_offset]);
-    for (i = (size_t)char_offset + 1; i < len; ++i) putchar(chrs[i]);
+    const int len = (int)strlen(text);
+    if (red < 0) red = 0;
+    printf("%*s", indent, "");
+    if (red < len) printf("%.*s\033[0;31m%c\033[0m%s", red, text, text[red], text + red + 1);
+    else printf("%s\033[0;31m\033[0m", text);
+    putchar('\n');
 }
 
 static void pretty_print(const ProgramData* data, const char* mut, int offset, int char_offset)
 {
     static char signs[PSA_SEQ2_MAX_LEN];
-    double score;
     int i;
     if (psa_build_tables(data->weights, data->is_max, g_pair, NULL, NULL, g_sign) != PSA_OK) return;
-    printf("\033[0;31m%s\033[0m problem\n", data->is_max ? "Maximum" : "Minimum");
-    printf("Weights: ");
+    printf("\033[0;31m%s\033[0m problem\nWeights: ", data->is_max ? "Maximum" : "Minimum");
     for (i = 0; i < PSA_NUM_WEIGHTS; ++i) printf("%g ", data->weights[i]);
-    if (offset == -1) {
-        printf("\n\033[0;31mThere are no mutations found\033[0m\n");
-        printf("%s\n%s\n", data->seq1, data->seq2);
+    if (offset < 0) {
+        printf("\n\033[0;31mThere are no mutations found\033[0m\n%s\n%s\n", data->seq1, data->seq2);
         return;
     }
-    score = score_and_signs(data->seq1, data->seq2, offset, signs);
-    printf("\nOriginal Score: %g\n", score);
-    print_with_offset(signs, offset, char_offset);
-    printf("\n");
-    print_with_offset(data->seq2, offset, char_offset);
-    printf("\n");
+    printf("\nOriginal Score: %g\n", signs_and_score(data->seq1, data->seq2, offset, signs));
+    aligned_row(signs, offset, char_offset);
+    aligned_row(data->seq2, offset, char_offset);
     printf("%s\n", data->seq1);
-    print_with_offset(mut, offset, char_offset);
-    printf("\n");
-    score = score_and_signs(data->seq1, mut, offset, signs);
-    print_with_offset(signs, offset, char_offset);
-    printf("\n");
-    printf("Mutation Score: %g\n", score);
-    printf("Seq offset=%3d, Char offset=%3d\n", offset, char_offset);
+    aligned_row(mut, offset, char_offset);
+    {
+        const double after = signs_and_score(data->seq1, mut, offset, signs);
+        aligned_row(signs, offset, char_offset);
+        printf("Mutation Score: %g\nSeq offset=%3d, Char offset=%3d\n", after, offset, char_offset);
+    }
 }
 
 /* the sign table as print_hash lays it out (cpu_funcs.c:322-349): header, rule, one row per symbol */
@@ -398,7 +404,7 @@ int main(int argc, char* argv[])
     printf("CUDA percentage set to %d\n", cuda_percentage);
 
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    score = divide_execute_tasks(&g_data, cuda_percentage, threads, &mutant);
+    score = run_split(&g_data, cuda_percentage, threads, &mutant);
     clock_gettime(CLOCK_MONOTONIC, &t1);
 
     strcpy(mut, g_data.seq2);
