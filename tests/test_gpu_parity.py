@@ -567,6 +567,26 @@ def test_batches_of_reference_sized_inputs_spread_over_query_blocks(psa, oracle,
         assert [r.shard for r in got] == list(range(nq))
 
 
+def test_stock_reference_caller_links_and_runs(psa, oracle, reference_records, tmp_path):
+    """tests/c/stock_caller.c declares the reference's own structs (10001 / 5001, 15,048 bytes) and prototype —
+    none of this repo's headers — and calls gpu_run_program by name, like cpu_funcs.c:180.  Linked against
+    libpsa_amd.so it gives output.txt's answer for the bundled input and the oracle's for a sub-range."""
+    import subprocess
+    from conftest import PKG, ROOT
+    exe = tmp_path / "stock_caller"
+    lib_dir = os.path.join(PKG, "psa_amd")
+    subprocess.run(["gcc", "-O2", "-std=c11", "-Wall", "-o", str(exe), os.path.join(ROOT, "tests", "c", "stock_caller.c"),
+                    "-L", lib_dir, "-lpsa_amd", f"-Wl,-rpath,{lib_dir}"], check=True, capture_output=True, text=True)
+    run = subprocess.run([str(exe), os.path.join(GOLDEN, "reference_input.txt")], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    lines = run.stdout.splitlines()
+    assert lines[0] == "4505 144 E -4879"
+    w, s1, s2, is_max = reference_records[0]
+    total = len(s1) - len(s2) + 1
+    score, off, ci, ch = oracle.search(s1, s2, w, is_max, total // 2, total, threads=4)
+    assert lines[1] == "%d %d %s %g" % (off, ci, ch, score)
+
+
 def test_filter_engine_synthetic_golden_and_ranges(psa, oracle):
     gold = json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))
     with psa.Context(0) as c:

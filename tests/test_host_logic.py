@@ -174,3 +174,14 @@ def test_drop_in_program_sign_table(psa):
     want = [ln for ln in want if "|" in ln]
     assert len(got) == 27 and got == want
     assert run.stdout.splitlines()[0].split() == list("ABCDEFGHIJKLMNOPQRSTUVWXYZ-")
+
+
+def test_stock_reference_caller_links(psa, tmp_path):
+    """The reference-style caller (its own structs and prototype, no header of this repo) compiles and links against
+    libpsa_amd.so by symbol name — the link-time half of the drop-in claim (the run is a GPU test)."""
+    import subprocess
+    from conftest import PKG, ROOT
+    lib_dir = os.path.join(PKG, "psa_amd")
+    subprocess.run(["gcc", "-O2", "-std=c11", "-Wall", "-Werror", "-o", str(tmp_path / "stock_caller"),
+                    os.path.join(ROOT, "tests", "c", "stock_caller.c"), "-L", lib_dir, "-lpsa_amd",
+                    f"-Wl,-rpath,{lib_dir}"], check=True, capture_output=True, text=True)
