@@ -52,6 +52,8 @@ HBM_PEAK_GBS = 8000.0                   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s sp
 VALU_PEAK = 1024 * 2.4e9 / 2            # wave64 instructions/s: 1024 SIMDs, one full-rate VALU op per 2 cycles at 2.4 GHz
 BYTES_PER_PAIR = 2                      # 1 B of Seq1 + 1 B of Seq2 per char pair
 SEED_SEQ1, SEED_QUERY0 = 1002, 2002
+PROFILE_LAUNCH_QUERIES = 128            # queries per launch of the batch count kernel (the library's default), and what the
+                                        # committed PMC passes ran with (tools/profile_round.sh: --queries 128)
 
 
 def parse_args(argv=None):
@@ -421,7 +423,7 @@ def main():
     single_kernel_s = kernel_ms / max(profiled, 1) / 1e3
     kernel_name, kernel_s, kernel_queries = single_kernel_name, single_kernel_s, 1
     if args.mode == "batch" and qhi - qlo >= 2:
-        probe = min(qhi - qlo, 32)
+        probe = min(qhi - qlo, PROFILE_LAUNCH_QUERIES)          # one launch of the batch kernel, as in the timed region
         times = []
         try:
             for k in range(6):
@@ -477,7 +479,7 @@ def main():
                     (("<" not in kernel_name) or kernel_name in row["kernel"]) and "seq" not in os.path.basename(cpath):
                 insts = float(row["mean_per_dispatch"])
                 if "duo" in kernel_name:
-                    insts *= kernel_queries / 32.0          # the profile's launches served 32 queries each
+                    insts *= kernel_queries / float(PROFILE_LAUNCH_QUERIES)   # the profile's launches served that many queries each
                 valu = {"wave_instructions_per_launch": insts, "achieved_per_s": insts / kernel_s,
                         "source": os.path.relpath(cpath, ROOT)}
                 break
