@@ -23,6 +23,11 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: only what this header declares (and the reference's C++-mangled
+ * name of gpu_run_program, see below) is exported. */
+#define PSA_EXPORT __attribute__((visibility("default")))
+#pragma GCC visibility push(default)
+
 typedef enum psa_status {
     PSA_OK            = 0,
     PSA_ERR_ARG       = 1,  /* null pointer, empty/negative range, n < m ... */
@@ -67,12 +72,22 @@ typedef struct psa_context psa_context;
  *
  * Layout.  A plain symbol cannot see how its caller compiled ProgramData, so the
  * library's gpu_run_program reads the reference's STOCK struct (def.h:35-36:
- * seq1[10001], seq2[5001], 15,048 bytes): an unmodified reference build that links
- * this library and calls gpu_run_program by name is served correctly.  A caller
- * compiled with other limits (this repo's own program uses 1,000,001 / 10,001)
- * must go through gpu_run_program_layout; including this header does that
- * automatically (the inline below), so `gpu_run_program(&data, ...)` is right for
- * whatever PSA_SEQ*_MAX_LEN the including translation unit was built with.
+ * seq1[10001], seq2[5001], 15,048 bytes).  A caller compiled with other limits
+ * (this repo's own program uses 1,000,001 / 10,001) must go through
+ * gpu_run_program_layout; including this header does that automatically (the
+ * inline below), so `gpu_run_program(&data, ...)` is right for whatever
+ * PSA_SEQ*_MAX_LEN the including translation unit was built with.  A caller that
+ * binds the plain symbol by name (dlsym, ctypes, its own prototype) with another
+ * layout is detected where that is possible — no NUL inside seq1[10001] /
+ * seq2[5001]: message on stderr and exit(EXIT_FAILURE); an empty seq2 at the stock
+ * offset: message on stderr, "nothing found" returned.
+ *
+ * Linkage.  The reference builds every file as C++ (Makefile:9-12) and declares no
+ * extern "C", so its objects refer to the Itanium-mangled
+ * _Z15gpu_run_programP5_dataP7_mutantii (cuda_funcs.h:33, call site
+ * cpu_funcs.c:180).  The library exports that name too (stock layout, same entry):
+ * an unmodified reference cpu_funcs.o links against libpsa_amd.so without an edit
+ * (tests/c/stock_caller.cpp).  C callers and this header use the plain C name.
  * ------------------------------------------------------------------------- */
 
 /* For a caller whose ProgramData was compiled with array limits seq1_cap /
@@ -112,6 +127,11 @@ psa_status psa_set_seq2(psa_context* ctx, const char* seq2, int m);
  * uint8 tensor's data_ptr); encoded in place on the context's stream. */
 psa_status psa_set_seq1_device(psa_context* ctx, const void* d_seq1, int n);
 psa_status psa_set_seq2_device(psa_context* ctx, const void* d_seq2, int m);
+
+/* Both sequences of a search at once: ONE encode launch (and, for host sequences that lie
+ * side by side like the two arrays of a ProgramData, one copy command). */
+psa_status psa_set_sequences(psa_context* ctx, const char* seq1, int n, const char* seq2, int m);
+psa_status psa_set_sequences_device(psa_context* ctx, const void* d_seq1, int n, const void* d_seq2, int m);
 
 psa_status psa_set_engine(psa_context* ctx, psa_engine engine);
 /* Batches: count launches stay on one stream (default 1: no two launches overlap, a profiler sees each launch's
@@ -168,6 +188,9 @@ int psa_fallback_count(psa_context* ctx);
  * against a running bound while the tiles finish; when that overflows the list, the selection
  * is repeated against the final bound (only a second overflow goes to the sequential engine). */
 int psa_reselect_count(psa_context* ctx);
+/* Single filter searches that needed a second launch (psa_rescore_kernel): a single search normally ends inside the
+ * count kernel, whose last workgroup re-scores up to 16 surviving candidates itself. */
+int psa_unfused_count(psa_context* ctx);
 /* Batches redone with the per-query count kernel because a wave-group barrier of the batch
  * count kernel gave up (never expected on a healthy device). */
 int psa_duo_retry_count(psa_context* ctx);
@@ -185,14 +208,23 @@ psa_status psa_debug_rescore(psa_context* ctx, const int32_t* offsets, int count
  * points use a group when PSA_DEVICES=0,1,... lists more than one device.
  * ------------------------------------------------------------------------- */
 typedef struct psa_group psa_group;
-psa_status psa_group_create(const int* devices, int ndev, psa_group** out);
+/* How the devices' records meet.  RCCL: one ncclAllGather over xGMI, one rank per GPU (a device may be listed
+ * once).  HOST: every device's record is copied to host memory — no RCCL; a device may be listed several times
+ * (one context each), which rehearses an N-way split on fewer GPUs (tests do on the one-GPU box). */
+#define PSA_EXCHANGE_RCCL 0
+#define PSA_EXCHANGE_HOST 1
+psa_status psa_group_create(const int* devices, int ndev, psa_group** out);             /* RCCL exchange */
+psa_status psa_group_create_ex(const int* devices, int ndev, int exchange, psa_group** out);
 void       psa_group_destroy(psa_group* g);
 int        psa_group_size(const psa_group* g);
 psa_status psa_group_set_weights(psa_group* g, const double weights[4], int is_max);
 psa_status psa_group_set_seq1(psa_group* g, const char* seq1, int n);   /* every device gets Seq1 (MPI_Bcast) */
 psa_status psa_group_set_seq2(psa_group* g, const char* seq2, int m);
 /* Offsets [first_offset,last_offset) over the group.  shard_records (optional, [ndev]) receives the
- * exchanged per-device records (shard = index in the group; offset -1 for an empty shard). */
+ * exchanged per-device records (shard = index in the group; offset -1 for an empty shard).  The last kernel of every
+ * device's search writes its record into the exchange's send buffer, the all-gather follows on the same stream, the
+ * host waits once (device 0's copy of the records).  The group entry points put the calling thread's current
+ * device back before they return. */
 psa_status psa_search_sharded(psa_group* g, int first_offset, int last_offset, psa_result* out,
                               psa_result* shard_records);
 
@@ -202,6 +234,17 @@ psa_status psa_search_sharded(psa_group* g, int first_offset, int last_offset, p
  * all-gather of the records.  Needs psa_group_set_weights and psa_group_set_seq1. */
 psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, int m, size_t stride,
                                     int first_offset, int last_offset, psa_result* results, psa_result* results_min);
+
+/* Host-only: how nq queries are dealt to nshards shards (psa_search_batch_sharded, bench.py): contiguous blocks as
+ * even as possible, the first nq % nshards shards take one query more.  (The reference has no batch; its offset rule
+ * — the last rank takes the remainder, psa_shard_range — would leave the last GPU up to nshards-1 extra queries.)
+ * psa_query_block_max = the largest block = records per shard and mode in the batch exchange. */
+void psa_query_block(int nq, int nshards, int rank, int* first_query, int* last_query);
+int  psa_query_block_max(int nq, int nshards);
+/* Host-only: the batch exchange's layout.  Every shard contributes a block of 2 * per records, [mode][per] with
+ * per = psa_query_block_max (unused entries are padding); `gathered` = the nshards blocks side by side.  Puts mode 0
+ * into results[nq] and mode 1 into results_min[nq] (may be NULL) in query order, shard = query index. */
+psa_status psa_batch_unpack(const psa_result* gathered, int nq, int nshards, psa_result* results, psa_result* results_min);
 
 /* Fold of per-shard records with the reference's merge order
  * (is_swapable, cuda_funcs.cu:290-307: strictly better score, then lower
@@ -239,6 +282,8 @@ void psa_generate_sequence(uint64_t seed, int n, char* out);
 
 const char* psa_last_error(void);
 const char* psa_version(void);
+
+#pragma GCC visibility pop
 
 #ifdef __cplusplus
 }

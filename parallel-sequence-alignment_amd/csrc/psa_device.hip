@@ -87,28 +87,6 @@ __device__ __forceinline__ void block_fold(bool is_max, double& s, int& o, int& 
 namespace psa {
 
 // ---------------------------------------------------------------------------
-// encode kernels: ASCII -> codes (psa_internal.hpp), flag anything else
-// ---------------------------------------------------------------------------
-__global__ void psa_encode_seq2(const unsigned char* __restrict__ raw, int m, unsigned int* __restrict__ rows,
-                                unsigned char* __restrict__ bytes, unsigned int* __restrict__ classes, int capacity,
-                                int class_chars, int class_total, int* __restrict__ bad)
-{
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= capacity) return;
-    int code = kCodePad;
-    if (i < m) {
-        const unsigned char c = raw[i];
-        code = (c >= 'A' && c <= 'Z') ? c - 'A' : (c == '-' ? kCodeHyphen : kCodeBad);
-        if (code == kCodeBad) { atomicOr(bad, 2); code = kCodePad; }
-    }
-    rows[i] = (unsigned int)code << kRowShift;    // symbol as a 4 KiB row offset; the sequential engine
-    bytes[i] = (unsigned char)code;               // shifts it back to a table row
-    // the same symbols in the count kernels' class order (psa_filter_kernels.hpp: class_index)
-    if (i < class_total) classes[class_index(i, class_chars)] = (unsigned int)code << kRowShift;
-    else if (i < class_total + kUnroll) classes[i] = (unsigned int)kCodePad << kRowShift;
-}
-
-// ---------------------------------------------------------------------------
 // sequential engine
 // ---------------------------------------------------------------------------
 struct SeqArgs {
@@ -215,7 +193,23 @@ struct FinalArgs {
     int is_max;
     int seq;
     long long pairs;
+    psa_result* record_out;      // device groups: the record also goes to device memory (shard = record_shard); or NULL
+    int record_shard;
 };
+
+__device__ __forceinline__ void finalize_write(const FinalArgs& a, psa_result r)
+{
+    r.shard = -1;
+    r.pairs = a.pairs;
+    a.out->result = r;
+    a.out->bad = *a.bad;
+    a.out->overflow = 0;
+    a.out->seq = a.seq;
+    if (a.record_out) {
+        r.shard = a.record_shard;
+        *a.record_out = r;
+    }
+}
 
 __global__ __launch_bounds__(kBlock) void psa_finalize_kernel(FinalArgs a)
 {
@@ -244,12 +238,7 @@ __global__ __launch_bounds__(kBlock) void psa_finalize_kernel(FinalArgs a)
             r.offset = -1;
             r.char_offset = -1;
             r.ch = 0;
-            r.shard = -1;
-            r.pairs = a.pairs;
-            a.out->result = r;
-            a.out->bad = *a.bad;
-            a.out->overflow = 0;
-            a.out->seq = a.seq;
+            finalize_write(a, r);
         }
         return;
     }
@@ -268,12 +257,7 @@ __global__ __launch_bounds__(kBlock) void psa_finalize_kernel(FinalArgs a)
         r.offset = w.offset;
         r.char_offset = i;
         r.ch = a.sub[idx];
-        r.shard = -1;
-        r.pairs = a.pairs;
-        a.out->result = r;
-        a.out->bad = *a.bad;
-        a.out->overflow = 0;
-        a.out->seq = a.seq;
+        finalize_write(a, r);
     }
 }
 
@@ -319,6 +303,16 @@ using psa::set_last_error;
     } while (0)
 
 namespace {
+
+// The library selects the device of the context it works on; an entry point puts the caller's current device back
+// when it returns (a host program with its own HIP / torch work on another GPU keeps launching there).
+struct DeviceScope {
+    int prev = -1;
+    DeviceScope() { if (hipGetDevice(&prev) != hipSuccess) prev = -1; }
+    ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceScope(const DeviceScope&) = delete;
+    DeviceScope& operator=(const DeviceScope&) = delete;
+};
 
 constexpr int kLdsLimit = 160 * 1024 - 1024;   // dynamic LDS a workgroup may ask for (the kernels keep < 1 KB static)
 constexpr int kCandCap = 2048;        // candidates re-scored per search before falling back
@@ -403,6 +397,7 @@ struct psa_context {
     int         n_cap = 0;
 
     unsigned char* d_raw = nullptr;  size_t raw_cap = 0;   // staging for host sequences
+    size_t         raw_second = 0;        // stage_host_pair: where the second sequence starts in d_raw
     unsigned char* d_s1 = nullptr;        // Seq1 codes, code-27 padded to n_cap
     int            nslots = 0;            // 32-symbol slots of d_s1
     double*        d_pair = nullptr;
@@ -456,7 +451,11 @@ struct psa_context {
     int         last_kernel_queries = 1;     // queries covered by the launch timed between ev[2] and ev[3]
     int         fallbacks = 0;               // filter searches redone by the sequential engine
     int         reselects = 0;               // filter searches whose selection ran twice (overflow against the running bound)
+    int         unfused = 0;                 // single filter searches finished by psa_rescore_kernel, not inside the count kernel
     int         seq = 0;                     // sequence number of the last search enqueued
+    // device groups: the final kernel of a single search also writes its 32-byte record here (device memory)
+    psa_result* record_out = nullptr;
+    int         record_shard = -1;
 };
 
 namespace {
@@ -553,7 +552,7 @@ psa_status report_bad(psa_context* c)
 }
 
 // Seq1: ASCII -> symbol codes (the class planes are built per workgroup inside the count kernel)
-psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
+psa_status seq1_args(psa_context* c, const void* d_raw, int n, psa::PrepareArgs* a)
 {
     const int need = (n + kSeq1Slack + 63) & ~63;
     if (need > c->n_cap) {
@@ -562,12 +561,18 @@ psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
         c->nslots = need / 32;
     }
     c->n = -1;
+    a->raw = static_cast<const unsigned char*>(d_raw);
+    a->codes = c->d_s1;
+    a->bad = c->d_bad;
+    a->n = n;
+    a->nslots = c->nslots;
+    return PSA_OK;
+}
+
+psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
+{
     psa::PrepareArgs a;
-    a.raw = static_cast<const unsigned char*>(d_raw);
-    a.codes = c->d_s1;
-    a.bad = c->d_bad;
-    a.n = n;
-    a.nslots = c->nslots;
+    PSA_TRY(seq1_args(c, d_raw, n, &a));
     hipLaunchKernelGGL(psa::psa_prepare_seq1_kernel, dim3((c->nslots + 255) / 256), dim3(256), 0, c->stream, a);
     PSA_HIP(hipGetLastError());
     c->n = n;
@@ -576,7 +581,8 @@ psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
 
 bool plan_filter(int first, int last, int m, FilterPlan* best, int max_chunks = 1 << 30);
 
-psa_status encode_seq2(psa_context* c, SearchSlot& s, const void* d_raw, int m, hipStream_t stream)
+// `n` = the Seq1 length the class order is planned for (the context's, or the one being set in the same launch)
+psa_status seq2_args(SearchSlot& s, const void* d_raw, int m, int n, int* d_bad, psa::Seq2Args* a, FilterPlan* p)
 {
     const int need = (m + kSeq2Slack + 63) & ~63;
     if (need > s.m_cap) {
@@ -588,19 +594,55 @@ psa_status encode_seq2(psa_context* c, SearchSlot& s, const void* d_raw, int m, 
     s.m = -1;
     // class order for the chunking a search over every offset will use (a search of another range
     // that plans differently re-orders them: ensure_class_order)
-    FilterPlan p;
-    const int total = c->n >= m ? c->n - m + 1 : psa::kTileStride * 256;
-    if (!plan_filter(0, total, m, &p)) { p.class_chars = 0; p.nchunks = 0; }
-    hipLaunchKernelGGL(psa::psa_encode_seq2, dim3((s.m_cap + 255) / 256), dim3(256), 0, stream,
-                       static_cast<const unsigned char*>(d_raw), m, s.d_s2rows, s.d_s2bytes, s.d_s2cls, s.m_cap,
-                       p.class_chars, p.nchunks * psa::kClasses * p.class_chars, c->d_bad);
-    PSA_HIP(hipGetLastError());
+    const int total = n >= m ? n - m + 1 : psa::kTileStride * 256;
+    if (!plan_filter(0, total, m, p)) { p->class_chars = 0; p->nchunks = 0; }
+    a->raw = static_cast<const unsigned char*>(d_raw);
+    a->rows = s.d_s2rows;
+    a->bytes = s.d_s2bytes;
+    a->classes = s.d_s2cls;
+    a->bad = d_bad;
+    a->m = m;
+    a->capacity = s.m_cap;
+    a->class_chars = p->class_chars;
+    a->class_total = p->nchunks * psa::kClasses * p->class_chars;
+    return PSA_OK;
+}
+
+void seq2_encoded(SearchSlot& s, int m, const FilterPlan& p)
+{
     s.m = m;
     s.cls_chars = p.class_chars;
     s.cls_chunks = p.nchunks;
     s.s2rows = s.d_s2rows;
     s.s2bytes = s.d_s2bytes;
     s.s2cls = s.d_s2cls;
+}
+
+psa_status encode_seq2(psa_context* c, SearchSlot& s, const void* d_raw, int m, hipStream_t stream)
+{
+    psa::Seq2Args a;
+    FilterPlan p;
+    PSA_TRY(seq2_args(s, d_raw, m, c->n, c->d_bad, &a, &p));
+    hipLaunchKernelGGL(psa::psa_encode_seq2_kernel, dim3((s.m_cap + 255) / 256), dim3(256), 0, stream, a);
+    PSA_HIP(hipGetLastError());
+    seq2_encoded(s, m, p);
+    return PSA_OK;
+}
+
+// both sequences of a search (slot 0) by one launch
+psa_status encode_pair(psa_context* c, const void* d_raw1, int n, const void* d_raw2, int m)
+{
+    SearchSlot& s = c->slot[0];
+    psa::PrepareArgs a1;
+    psa::Seq2Args a2;
+    FilterPlan p;
+    PSA_TRY(seq1_args(c, d_raw1, n, &a1));
+    PSA_TRY(seq2_args(s, d_raw2, m, n, c->d_bad, &a2, &p));
+    const int blocks1 = (c->nslots + 255) / 256, blocks2 = (s.m_cap + 255) / 256;
+    hipLaunchKernelGGL(psa::psa_encode_pair_kernel, dim3(blocks1 + blocks2), dim3(256), 0, c->stream, a1, a2, blocks1);
+    PSA_HIP(hipGetLastError());
+    c->n = n;
+    seq2_encoded(s, m, p);
     return PSA_OK;
 }
 
@@ -625,6 +667,28 @@ psa_status stage_host(psa_context* c, const char* host, size_t len)
         c->raw_cap = len + 64;
     }
     PSA_HIP(hipMemcpyAsync(c->d_raw, host, len, hipMemcpyHostToDevice, c->stream));
+    return PSA_OK;
+}
+
+// Both sequences into the staging buffer.  Sequences that lie close together in host memory (the two arrays of a
+// ProgramData) travel as ONE copy command, gap included; raw_second = where the second one starts in d_raw.
+psa_status stage_host_pair(psa_context* c, const char* a, size_t na, const char* b, size_t nb)
+{
+    const bool adjacent = b >= a + na && (size_t)(b - a) + nb <= na + nb + 4096;
+    const size_t second = adjacent ? (size_t)(b - a) : ((na + 63) & ~(size_t)63);
+    const size_t len = second + nb;
+    if (len > c->raw_cap) {
+        c->raw_cap = 0;
+        PSA_TRY(dev_alloc(&c->d_raw, len + 64));
+        c->raw_cap = len + 64;
+    }
+    if (adjacent) {
+        PSA_HIP(hipMemcpyAsync(c->d_raw, a, len, hipMemcpyHostToDevice, c->stream));
+    } else {
+        PSA_HIP(hipMemcpyAsync(c->d_raw, a, na, hipMemcpyHostToDevice, c->stream));
+        PSA_HIP(hipMemcpyAsync(c->d_raw + second, b, nb, hipMemcpyHostToDevice, c->stream));
+    }
+    c->raw_second = second;
     return PSA_OK;
 }
 
@@ -712,6 +776,8 @@ psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last,
     f.is_max = ts.t->is_max;
     f.seq = c->seq;
     f.pairs = (long long)span * (long long)s.m;
+    f.record_out = c->record_out;
+    f.record_shard = c->record_shard;
     hipLaunchKernelGGL(psa::psa_finalize_kernel, dim3(1), dim3(psa::kBlock), 0, stream, f);
     PSA_HIP(hipGetLastError());
     return PSA_OK;
@@ -809,12 +875,70 @@ psa::BoundParams bound_params(const psa::Tables& t, int m)
     return b;
 }
 
+// What the exact re-score of a search's candidates needs — psa_rescore_kernel's arguments, also handed to the count
+// kernel of a single search, whose last workgroup does that work itself (finish_search).
+psa::RescoreArgs rescore_args(const psa_context* c, const SearchSlot& s, long long pairs, const TableSet& ts)
+{
+    const psa::Tables& t = *ts.t;
+    psa::RescoreArgs r;
+    r.s1 = c->d_s1;
+    r.s2 = s.s2bytes;
+    r.clsrank = ts.d_clsrank;
+    r.sub = ts.d_sub;
+    r.delta_of_rank = ts.d_delta;
+    r.cand = s.d_cand;
+    r.cand_upper = s.inline_select ? s.d_cand_upper : nullptr;
+    r.global_best = &s.d_scal->global_best;
+    r.cand_count = &s.d_scal->cand_count;
+    r.rec = s.d_rec;
+    r.done = &s.d_scal->done;
+    r.out = s.d_tail;
+    r.bad = c->d_bad;
+    r.pairs = pairs;
+    r.seq = c->seq;
+    r.class_value[0] = t.weights[0];       // get_weight, cuda_funcs.cu:442-452
+    r.class_value[1] = -t.weights[1];
+    r.class_value[2] = -t.weights[2];
+    r.class_value[3] = -t.weights[3];
+    for (int i = 4; i < 8; ++i) r.class_value[i] = 0.0;
+    r.m = s.m;
+    r.cap = kCandCap;
+    r.is_max = t.is_max;
+    {
+        // the integer walk needs normal (or zero) addends and a running sum at least two
+        // binades above the largest of them
+        int max_exp = 0;
+        bool ok = true;
+        for (int i = 0; i < 4; ++i) {
+            unsigned long long bits;
+            std::memcpy(&bits, &r.class_value[i], sizeof bits);
+            const int e = (int)((bits >> 52) & 0x7ff);
+            if (e == 0 && (bits << 1) != 0) ok = false;          // subnormal weight
+            if (e > max_exp) max_exp = e;
+        }
+#ifdef PSA_EXPERIMENT
+        static const bool chain_only = std::getenv("PSA_RESCORE_CHAIN") != nullptr;   // experiment knob
+#else
+        constexpr bool chain_only = false;
+#endif
+        r.fast_ok = ok && !chain_only;
+        r.fast_min_exp = max_exp + 2;
+    }
+    r.batched = 0;
+    r.s2_stride = 0;
+    r.record_out = nullptr;
+    r.record_shard = -1;
+    return r;
+}
+
 // first/span describe the searched range when the kernel should also produce the score
 // bounds (single-chunk plans); span = 0 writes raw partial counts instead.
 // `s2`/`ts2` (optional): a second search of the same Seq2 in another mode, selected in the same pass.
+// `fused`: a single search that ends inside this launch (the last tile workgroup re-scores the candidates and writes
+// the tail); otherwise psa_rescore_kernel follows.
 psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int base, int span_pad, int first,
                         int span, bool inline_select, hipStream_t stream, const TableSet& ts,
-                        const SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr)
+                        const SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr, bool fused = false)
 {
     if (p.nchunks > 1 && inline_select && !s.d_arrivals) { set_last_error("internal: no arrival counters"); return PSA_ERR_STATE; }
     psa::CountArgs a;
@@ -846,6 +970,11 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
         a.sel[1].cand_count = &s2->d_scal->cand_count;
         a.sel[1].bounds = bound_params(*ts2->t, s.m);
     }
+    a.fused = fused ? 1 : 0;
+    a.lds_bytes = p.lds_bytes;
+    a.tail = rescore_args(c, s, (long long)span * s.m, ts);
+    a.tail.record_out = c->record_out;
+    a.tail.record_shard = c->record_shard;
     const dim3 grid(p.ntiles, p.nchunks);
     // dynamic LDS above 64 KB has to be granted per kernel (and device: the flags live in the context)
     if (p.lds_bytes > c->granted16) {
@@ -968,7 +1097,8 @@ psa_status plan_on_slot(SearchSlot& s, int first, int last, hipStream_t stream, 
 
 // count + bounds + candidate selection: one kernel (chunk workgroups of a tile combine in the kernel)
 psa_status launch_filter_front(psa_context* c, SearchSlot& s, const FilterPlan& p, int first, int last, hipStream_t stream,
-                               bool profile, const TableSet& ts, SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr)
+                               bool profile, const TableSet& ts, SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr,
+                               bool fused = false)
 {
     const int span = last - first;
     const int base = first & ~31;
@@ -976,7 +1106,7 @@ psa_status launch_filter_front(psa_context* c, SearchSlot& s, const FilterPlan& 
     s.inline_select = true;
     if (s2) s2->inline_select = true;
     if (profile) PSA_HIP(hipEventRecord(c->ev[2], stream));
-    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, true, stream, ts, s2, ts2));
+    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, true, stream, ts, s2, ts2, fused));
     if (profile) PSA_HIP(hipEventRecord(c->ev[3], stream));
     return PSA_OK;
 }
@@ -986,50 +1116,10 @@ psa_status launch_filter_front(psa_context* c, SearchSlot& s, const FilterPlan& 
 psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hipStream_t stream, const TableSet& ts,
                               int grid = psa::kRescoreGrid, int batch = 0, size_t s2_stride = 0)
 {
-    const psa::Tables& t = *ts.t;
-    psa::RescoreArgs r;
-    r.s1 = c->d_s1;
-    r.s2 = s.s2bytes;
-    r.clsrank = ts.d_clsrank;
-    r.sub = ts.d_sub;
-    r.delta_of_rank = ts.d_delta;
-    r.cand = s.d_cand;
-    r.cand_upper = s.inline_select ? s.d_cand_upper : nullptr;
-    r.global_best = &s.d_scal->global_best;
-    r.cand_count = &s.d_scal->cand_count;
-    r.rec = s.d_rec;
-    r.done = &s.d_scal->done;
-    r.out = s.d_tail;
-    r.bad = c->d_bad;
-    r.pairs = pairs;
-    r.seq = c->seq;
-    r.class_value[0] = t.weights[0];       // get_weight, cuda_funcs.cu:442-452
-    r.class_value[1] = -t.weights[1];
-    r.class_value[2] = -t.weights[2];
-    r.class_value[3] = -t.weights[3];
-    for (int i = 4; i < 8; ++i) r.class_value[i] = 0.0;
-    r.m = s.m;
-    r.cap = kCandCap;
-    r.is_max = t.is_max;
-    {
-        // the integer walk needs normal (or zero) addends and a running sum at least two
-        // binades above the largest of them
-        int max_exp = 0;
-        bool ok = true;
-        for (int i = 0; i < 4; ++i) {
-            unsigned long long bits;
-            std::memcpy(&bits, &r.class_value[i], sizeof bits);
-            const int e = (int)((bits >> 52) & 0x7ff);
-            if (e == 0 && (bits << 1) != 0) ok = false;          // subnormal weight
-            if (e > max_exp) max_exp = e;
-        }
-#ifdef PSA_EXPERIMENT
-        static const bool chain_only = std::getenv("PSA_RESCORE_CHAIN") != nullptr;   // experiment knob
-#else
-        constexpr bool chain_only = false;
-#endif
-        r.fast_ok = ok && !chain_only;
-        r.fast_min_exp = max_exp + 2;
+    psa::RescoreArgs r = rescore_args(c, s, pairs, ts);
+    if (batch == 0) {
+        r.record_out = c->record_out;
+        r.record_shard = c->record_shard;
     }
     if (!c->granted_rescore) {
         PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_rescore_kernel),
@@ -1141,6 +1231,7 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     if (device < 0 || device >= count) { set_last_error("psa_create: device index out of range"); return PSA_ERR_ARG; }
     psa_context* c = new psa_context();
     c->device = device;
+    DeviceScope device_scope;
     psa_status st = [&]() -> psa_status {
         PSA_HIP(hipSetDevice(device));
         if (stream) c->stream = static_cast<hipStream_t>(stream);
@@ -1200,6 +1291,7 @@ psa_status psa_create(int device, void* stream, psa_context** out)
 void psa_destroy(psa_context* c)
 {
     if (!c) return;
+    DeviceScope device_scope;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->aux) (void)hipStreamSynchronize(c->aux);
@@ -1250,6 +1342,7 @@ psa_status psa_set_weights(psa_context* c, const double weights[4], int is_max)
     std::string err;
     psa::Tables t;
     if (!psa::build_tables(weights, is_max, &t, &err)) { set_last_error(err); return PSA_ERR_ARG; }
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     c->tables = t;
     c->have_alt = false;
@@ -1261,6 +1354,7 @@ psa_status psa_set_weights(psa_context* c, const double weights[4], int is_max)
 psa_status psa_set_seq1_device(psa_context* c, const void* d_seq1, int n)
 {
     if (!c || !d_seq1 || n < 1) { set_last_error("psa_set_seq1: bad arguments"); return PSA_ERR_ARG; }
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     return encode_seq1(c, d_seq1, n);      // alphabet errors surface at psa_search_wait
 }
@@ -1268,6 +1362,7 @@ psa_status psa_set_seq1_device(psa_context* c, const void* d_seq1, int n)
 psa_status psa_set_seq2_device(psa_context* c, const void* d_seq2, int m)
 {
     if (!c || !d_seq2 || m < 1) { set_last_error("psa_set_seq2: bad arguments"); return PSA_ERR_ARG; }
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     return encode_seq2(c, c->slot[0], d_seq2, m, c->stream);
 }
@@ -1275,6 +1370,7 @@ psa_status psa_set_seq2_device(psa_context* c, const void* d_seq2, int m)
 psa_status psa_set_seq1(psa_context* c, const char* seq1, int n)
 {
     if (!c || !seq1 || n < 1) { set_last_error("psa_set_seq1: bad arguments"); return PSA_ERR_ARG; }
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     PSA_TRY(stage_host(c, seq1, (size_t)n));
     PSA_TRY(encode_seq1(c, c->d_raw, n));
@@ -1285,9 +1381,30 @@ psa_status psa_set_seq1(psa_context* c, const char* seq1, int n)
 psa_status psa_set_seq2(psa_context* c, const char* seq2, int m)
 {
     if (!c || !seq2 || m < 1) { set_last_error("psa_set_seq2: bad arguments"); return PSA_ERR_ARG; }
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     PSA_TRY(stage_host(c, seq2, (size_t)m));
     PSA_TRY(encode_seq2(c, c->slot[0], c->d_raw, m, c->stream));
+    PSA_TRY(check_bad_now(c));
+    return report_bad(c);
+}
+
+// Both sequences of a search at once: one copy command each (host variant) and ONE encode launch.
+psa_status psa_set_sequences_device(psa_context* c, const void* d_seq1, int n, const void* d_seq2, int m)
+{
+    if (!c || !d_seq1 || !d_seq2 || n < 1 || m < 1) { set_last_error("psa_set_sequences: bad arguments"); return PSA_ERR_ARG; }
+    DeviceScope device_scope;
+    PSA_TRY(ensure_device(c));
+    return encode_pair(c, d_seq1, n, d_seq2, m);      // alphabet errors surface at psa_search_wait
+}
+
+psa_status psa_set_sequences(psa_context* c, const char* seq1, int n, const char* seq2, int m)
+{
+    if (!c || !seq1 || !seq2 || n < 1 || m < 1) { set_last_error("psa_set_sequences: bad arguments"); return PSA_ERR_ARG; }
+    DeviceScope device_scope;
+    PSA_TRY(ensure_device(c));
+    PSA_TRY(stage_host_pair(c, seq1, (size_t)n, seq2, (size_t)m));
+    PSA_TRY(encode_pair(c, c->d_raw, n, c->d_raw + c->raw_second, m));
     PSA_TRY(check_bad_now(c));
     return report_bad(c);
 }
@@ -1309,29 +1426,46 @@ psa_status psa_set_engine(psa_context* c, psa_engine engine)
     return PSA_OK;
 }
 
-psa_status psa_search_async(psa_context* c, int first, int last)
+// One filter search on slot 0 = ONE launch: the count kernel's last tile workgroup re-scores the candidates and
+// writes the tail (finish_search).  Only a Seq2 whose class codes do not fit that workgroup's LDS is followed by
+// psa_rescore_kernel right away.
+static psa_status enqueue_filter_search(psa_context* c, int first, int last, bool profile)
+{
+    SearchSlot& s = c->slot[0];
+    FilterPlan plan;
+    PSA_TRY(plan_on_slot(s, first, last, c->stream, &plan));
+    const bool fused = psa::fused_candidates_at_a_time(plan.lds_bytes, s.m) >= 1;
+    PSA_TRY(launch_filter_front(c, s, plan, first, last, c->stream, profile, primary_tables(c), nullptr, nullptr, fused));
+    if (!fused) {
+        c->unfused += 1;
+        PSA_TRY(launch_filter_back(c, s, (long long)(last - first) * s.m, c->stream, primary_tables(c)));
+    }
+    return PSA_OK;
+}
+
+static psa_status search_async_impl(psa_context* c, int first, int last, psa_result* record_out, int record_shard)
 {
     if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
     SearchSlot& s = c->slot[0];
     PSA_TRY(check_ready(c, s.m, first, last));
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     c->timing_valid = false;
     c->seq += 1;
     s.d_tail = c->hd_tails;
+    c->record_out = record_out;
+    c->record_shard = record_shard;
     if (c->profiling) PSA_HIP(hipEventRecord(c->ev[0], c->stream));
     c->last_kernel_queries = 1;
     c->pending_filter = use_filter(c, first, last, s.m);
     c->pending_first = first;
     c->pending_last = last;
     if (c->pending_filter) {
-        // the re-score kernel's last workgroup leaves the scalars zeroed; only a search that was
-        // enqueued but never waited for (or failed) can have left them dirty
+        // the search's last workgroup leaves the scalars zeroed; only a search that was enqueued but never
+        // waited for, failed or fell back can have left them dirty
         if (s.scal_dirty) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
         s.scal_dirty = true;
-        FilterPlan plan;
-        PSA_TRY(plan_on_slot(s, first, last, c->stream, &plan));
-        PSA_TRY(launch_filter_front(c, s, plan, first, last, c->stream, c->profiling, primary_tables(c)));
-        PSA_TRY(launch_filter_back(c, s, (long long)(last - first) * s.m, c->stream, primary_tables(c)));
+        PSA_TRY(enqueue_filter_search(c, first, last, c->profiling));
     } else {
         PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream, primary_tables(c)));
     }
@@ -1343,43 +1477,69 @@ psa_status psa_search_async(psa_context* c, int first, int last)
     return PSA_OK;
 }
 
+psa_status psa_search_async(psa_context* c, int first, int last)
+{
+    return search_async_impl(c, first, last, nullptr, -1);
+}
+
+// The search in flight has been synchronised with: look at its tail and do what it asks for.
+//   overflow 2  more surviving candidates than the count kernel's last workgroup takes: psa_rescore_kernel on the lists.
+//   overflow 1  the candidate list did not hold everything picked against the RUNNING bound.  The bound left in the
+//               search scalars is final now, so the selection runs once more against it; only if that overflows too
+//               (more true near-ties than the list holds, e.g. a homopolymer) every offset is scored in reference
+//               order by the sequential engine.
+//   a tail that does not echo this search's number: no workgroup finished it (cannot happen for finite scores):
+//               sequential engine as well.
+static psa_status settle_search(psa_context* c)
+{
+    SearchSlot& s = c->slot[0];
+    const long long pairs = (long long)(c->pending_last - c->pending_first) * s.m;
+    *c->h_bad = c->h_tails[0].bad;
+    PSA_TRY(report_bad(c));                   // device-resident sequences are validated here
+    if (!c->pending_filter) return PSA_OK;
+    auto stale = [&]() { return c->h_tails[0].seq != c->seq; };
+    auto rescore_if_asked = [&]() -> psa_status {
+        if (stale() || c->h_tails[0].overflow != 2) return PSA_OK;
+        c->timing_valid = false;
+        c->unfused += 1;
+        PSA_TRY(launch_filter_back(c, s, pairs, c->stream, primary_tables(c)));
+        PSA_HIP(hipStreamSynchronize(c->stream));
+        return PSA_OK;
+    };
+    PSA_TRY(rescore_if_asked());
+    if (!stale() && c->h_tails[0].overflow == 1) {
+        c->reselects += 1;
+        c->seq += 1;
+        c->timing_valid = false;
+        PSA_TRY(enqueue_filter_search(c, c->pending_first, c->pending_last, false));
+        PSA_HIP(hipStreamSynchronize(c->stream));
+        PSA_TRY(rescore_if_asked());
+    }
+    if (stale() || c->h_tails[0].overflow) {
+        c->fallbacks += 1;                        // (the bound is still in the scalars: scal_dirty stays set)
+        c->seq += 1;
+        c->timing_valid = false;
+        PSA_TRY(launch_sequential(c, s, c->pending_first, c->pending_last, nullptr, nullptr, c->stream, primary_tables(c)));
+        PSA_HIP(hipStreamSynchronize(c->stream));
+    } else {
+        s.scal_dirty = false;                     // the search ran to its end: its last workgroup zeroed the scalars
+    }
+    return PSA_OK;
+}
+
 psa_status psa_search_wait(psa_context* c, psa_result* out)
 {
     if (!c || !out) { set_last_error("psa_search_wait: NULL argument"); return PSA_ERR_ARG; }
     if (!c->pending) { set_last_error("psa_search_wait: no search in flight"); return PSA_ERR_STATE; }
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));                // (a group waits for several devices' searches in turn; the retry
-                                              // paths below launch kernels)
+                                              // paths launch kernels)
     PSA_HIP(hipStreamSynchronize(c->stream));
     c->pending = false;
-    c->slot[0].scal_dirty = false;            // the search ran to its end: scalars are zero again
-    *c->h_bad = c->h_tails[0].bad;
-    PSA_TRY(report_bad(c));                   // device-resident sequences are validated here
-    // overflow: the candidate list did not hold everything picked against the RUNNING bound.  The bound
-    // left in the search scalars is final now, so the selection runs once more against it; only if that
-    // overflows too (more true near-ties than the list holds, e.g. a homopolymer) every offset is scored
-    // in reference order by the sequential engine.  A tail that does not echo this search's number means
-    // no candidate workgroup ran (cannot happen for finite scores): sequential engine as well.
-    bool stale = c->h_tails[0].seq != c->seq;
-    if (c->pending_filter && c->h_tails[0].overflow && !stale) {
-        SearchSlot& s = c->slot[0];
-        c->reselects += 1;
-        c->seq += 1;
-        c->timing_valid = false;
-        FilterPlan plan;
-        PSA_TRY(plan_on_slot(s, c->pending_first, c->pending_last, c->stream, &plan));
-        PSA_TRY(launch_filter_front(c, s, plan, c->pending_first, c->pending_last, c->stream, false, primary_tables(c)));
-        PSA_TRY(launch_filter_back(c, s, (long long)(c->pending_last - c->pending_first) * s.m, c->stream, primary_tables(c)));
-        PSA_HIP(hipStreamSynchronize(c->stream));
-        stale = c->h_tails[0].seq != c->seq;
-    }
-    if (c->pending_filter && (c->h_tails[0].overflow || stale)) {
-        c->slot[0].scal_dirty = true;             // the bound is still in the scalars
-        c->fallbacks += 1;
-        c->seq += 1;
-        PSA_TRY(launch_sequential(c, c->slot[0], c->pending_first, c->pending_last, nullptr, nullptr, c->stream, primary_tables(c)));
-        PSA_HIP(hipStreamSynchronize(c->stream));
-        c->timing_valid = false;
-    }
+    const psa_status st = settle_search(c);
+    c->record_out = nullptr;
+    c->record_shard = -1;
+    PSA_TRY(st);
     *out = c->h_tails[0].result;
     if (c->profiling && c->timing_valid) {
         float a = 0.f, b = 0.f;
@@ -1415,6 +1575,7 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
     }
     if (c->pending) { set_last_error("psa_search_batch: a psa_search_async is still in flight"); return PSA_ERR_STATE; }
     PSA_TRY(check_ready(c, m, first, last));
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     const int nmodes = results1 ? 2 : 1;
     if (nmodes == 2) PSA_TRY(ensure_alt_tables(c));
@@ -1643,6 +1804,7 @@ psa_status psa_search_batch(psa_context* c, const char* queries, int nq, int m, 
                             int first, int last, psa_result* results)
 {
     if (!c || !queries || nq < 1 || stride < (size_t)m) { set_last_error("psa_search_batch: bad arguments"); return PSA_ERR_ARG; }
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     PSA_TRY(stage_host(c, queries, (size_t)(nq - 1) * stride + (size_t)m));
     PSA_HIP(hipStreamSynchronize(c->stream));
@@ -1662,6 +1824,7 @@ psa_status psa_search_batch_minmax(psa_context* c, const char* queries, int nq, 
                                    int first, int last, psa_result* results_max, psa_result* results_min)
 {
     if (!c || !queries || nq < 1 || stride < (size_t)m) { set_last_error("psa_search_batch_minmax: bad arguments"); return PSA_ERR_ARG; }
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     PSA_TRY(stage_host(c, queries, (size_t)(nq - 1) * stride + (size_t)m));
     PSA_HIP(hipStreamSynchronize(c->stream));
@@ -1673,6 +1836,7 @@ psa_status psa_scores(psa_context* c, int first, int last, double* scores, int32
     if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
     SearchSlot& s = c->slot[0];
     PSA_TRY(check_ready(c, s.m, first, last));
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     const int span = last - first;
     double* d_score = nullptr;
@@ -1710,6 +1874,7 @@ psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_sta
     if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
     SearchSlot& s = c->slot[0];
     PSA_TRY(check_ready(c, s.m, first, last));
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     const int span = last - first;
     const int base = first & ~31;
@@ -1762,6 +1927,7 @@ psa_status psa_debug_rescore(psa_context* c, const int32_t* offsets, int count, 
     }
     SearchSlot& s = c->slot[0];
     PSA_TRY(check_ready(c, s.m, 0, 1));
+    DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     const int total = c->n - s.m + 1;
     for (int k = 0; k < count; ++k)
@@ -1824,6 +1990,10 @@ int psa_fallback_count(psa_context* c) { return c ? c->fallbacks : 0; }
 // How many filter searches ran their candidate selection twice: the first pass picks against a running
 // bound and overflowed the list, the second against the final bound (tests).
 int psa_reselect_count(psa_context* c) { return c ? c->reselects : 0; }
+
+// Single filter searches of this context that psa_rescore_kernel finished (a second launch): more surviving candidates
+// than the count kernel's last workgroup re-scores itself (16), or a Seq2 whose class codes do not fit its LDS.
+int psa_unfused_count(psa_context* c) { return c ? c->unfused : 0; }
 
 // Batches this context ran a second time without the batch count kernel because one of its wave-group
 // barriers timed out (never expected; the debug library can force it: PSA_DUO_FORCE_TIMEOUT).
@@ -1893,11 +2063,12 @@ bool load_rccl(std::string* err)
 struct psa_group {
     std::vector<int>          devices;
     std::vector<psa_context*> ctx;
-    std::vector<ncclComm_t>   comm;
-    std::vector<psa_result*>  d_send;     // per device: its 32-byte record
+    int                       exchange = PSA_EXCHANGE_RCCL;
+    std::vector<ncclComm_t>   comm;       // RCCL exchange only
+    std::vector<psa_result*>  d_send;     // per device: its 32-byte record, written by the search's last kernel
     std::vector<psa_result*>  d_recv;     // per device: all ndev records after the exchange
-    psa_result*               h_send = nullptr;   // pinned [ndev]
-    psa_result*               h_recv = nullptr;   // pinned [ndev][ndev]
+    psa_result*               h_send = nullptr;   // pinned [ndev]: records of empty shards (written by the host)
+    psa_result*               h_recv = nullptr;   // pinned [ndev]: the exchanged records (device 0's copy)
     // batches: per device a block of `per` records per mode in, all ndev blocks out
     std::vector<psa_result*>  d_bsend, d_brecv;
     psa_result*               h_bsend = nullptr;  // pinned [ndev][2 * per]
@@ -1910,27 +2081,35 @@ struct psa_group {
 
 extern "C" {
 
-psa_status psa_group_create(const int* devices, int ndev, psa_group** out)
+psa_status psa_group_create_ex(const int* devices, int ndev, int exchange, psa_group** out)
 {
-    if (!out || !devices || ndev < 1) { set_last_error("psa_group_create: bad arguments"); return PSA_ERR_ARG; }
+    if (!out || !devices || ndev < 1 || (exchange != PSA_EXCHANGE_RCCL && exchange != PSA_EXCHANGE_HOST)) {
+        set_last_error("psa_group_create: bad arguments");
+        return PSA_ERR_ARG;
+    }
     *out = nullptr;
-    for (int i = 0; i < ndev; ++i)
-        for (int k = 0; k < i; ++k)
-            if (devices[i] == devices[k]) { set_last_error("psa_group_create: a device is listed twice"); return PSA_ERR_ARG; }
+    if (exchange == PSA_EXCHANGE_RCCL)          // (RCCL wants one rank per GPU; the host exchange takes several contexts on one)
+        for (int i = 0; i < ndev; ++i)
+            for (int k = 0; k < i; ++k)
+                if (devices[i] == devices[k]) { set_last_error("psa_group_create: a device is listed twice"); return PSA_ERR_ARG; }
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1) { set_last_error("no HIP device available"); return PSA_ERR_DEVICE; }
     std::string err;
-    if (!load_rccl(&err)) { set_last_error(err); return PSA_ERR_DEVICE; }
+    if (exchange == PSA_EXCHANGE_RCCL && !load_rccl(&err)) { set_last_error(err); return PSA_ERR_DEVICE; }
+    DeviceScope device_scope;
     psa_group* g = new psa_group();
     g->devices.assign(devices, devices + ndev);
+    g->exchange = exchange;
     psa_status st = [&]() -> psa_status {
         for (int i = 0; i < ndev; ++i) {
             psa_context* c = nullptr;
             PSA_TRY(psa_create(devices[i], nullptr, &c));
             g->ctx.push_back(c);
         }
-        g->comm.assign((size_t)ndev, nullptr);
-        PSA_NCCL(g_rccl.comm_init_all(g->comm.data(), ndev, devices));          // one communicator over the listed GPUs (xGMI)
+        if (exchange == PSA_EXCHANGE_RCCL) {
+            g->comm.assign((size_t)ndev, nullptr);
+            PSA_NCCL(g_rccl.comm_init_all(g->comm.data(), ndev, devices));      // one communicator over the listed GPUs (xGMI)
+        }
         g->d_send.assign((size_t)ndev, nullptr);
         g->d_recv.assign((size_t)ndev, nullptr);
         for (int i = 0; i < ndev; ++i) {
@@ -1939,7 +2118,7 @@ psa_status psa_group_create(const int* devices, int ndev, psa_group** out)
             PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_recv[i]), sizeof(psa_result) * (size_t)ndev));
         }
         PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_send), sizeof(psa_result) * (size_t)ndev, hipHostMallocPortable));
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_recv), sizeof(psa_result) * (size_t)ndev * ndev, hipHostMallocPortable));
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_recv), sizeof(psa_result) * (size_t)ndev, hipHostMallocPortable));
         return PSA_OK;
     }();
     if (st != PSA_OK) { psa_group_destroy(g); return st; }
@@ -1947,9 +2126,15 @@ psa_status psa_group_create(const int* devices, int ndev, psa_group** out)
     return PSA_OK;
 }
 
+psa_status psa_group_create(const int* devices, int ndev, psa_group** out)
+{
+    return psa_group_create_ex(devices, ndev, PSA_EXCHANGE_RCCL, out);
+}
+
 void psa_group_destroy(psa_group* g)
 {
     if (!g) return;
+    DeviceScope device_scope;
     for (size_t i = 0; i < g->comm.size(); ++i)
         if (g->comm[i]) (void)g_rccl.comm_destroy(g->comm[i]);
     for (size_t i = 0; i < g->d_send.size(); ++i) {
@@ -1975,6 +2160,7 @@ int psa_group_size(const psa_group* g) { return g ? (int)g->ctx.size() : 0; }
 psa_status psa_group_set_weights(psa_group* g, const double weights[4], int is_max)
 {
     if (!g) { set_last_error("group is NULL"); return PSA_ERR_ARG; }
+    DeviceScope device_scope;
     for (psa_context* c : g->ctx) PSA_TRY(psa_set_weights(c, weights, is_max));
     g->is_max = is_max ? 1 : 0;
     g->have_weights = true;
@@ -1987,6 +2173,7 @@ psa_status psa_group_set_weights(psa_group* g, const double weights[4], int is_m
 static psa_status group_set_seq(psa_group* g, const char* seq, int len, bool first_seq)
 {
     if (!g || !seq || len < 1) { set_last_error("psa_group_set_seq: bad arguments"); return PSA_ERR_ARG; }
+    DeviceScope device_scope;
     for (psa_context* c : g->ctx) {
         PSA_TRY(ensure_device(c));
         PSA_TRY(stage_host(c, seq, (size_t)len));
@@ -2009,6 +2196,10 @@ psa_status psa_group_set_seq2(psa_group* g, const char* seq2, int m) { return gr
 // cpu_funcs.c:128-133), all shards searched concurrently, ONE RCCL all-gather of the 32-byte records
 // (in place of MPI_Allreduce(MAXLOC|MINLOC) + MPI_Send/Recv of the Mutant, cpu_funcs.c:71-94), then the
 // is_swapable fold (ties: lowest offset = lowest shard, like MPI_MAXLOC's lowest rank).
+// The host is not in the middle: the last kernel of every device's search writes its record straight into the
+// exchange's send buffer, the all-gather follows on the same stream, and the host waits once, for device 0's copy
+// of the gathered records.  A record tagged "look again" (candidate-list overflow, more survivors than the count
+// kernel's last workgroup takes) sends that device's search through the single-context retry path.
 psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out, psa_result* shard_records)
 {
     if (!g || !out) { set_last_error("psa_search_sharded: NULL argument"); return PSA_ERR_ARG; }
@@ -2018,55 +2209,78 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
     }
     const int ndev = (int)g->ctx.size();
     PSA_TRY(check_ready(g->ctx[0], g->m, first, last));
+    DeviceScope device_scope;
     const int total = last - first;
-    std::vector<int> lo((size_t)ndev), hi((size_t)ndev);
+    std::vector<int> lo((size_t)ndev), hi((size_t)ndev), tag((size_t)ndev);
     for (int i = 0; i < ndev; ++i) {
+        psa_context* c = g->ctx[i];
         psa_shard_range(total, ndev, i, &lo[i], &hi[i]);
         lo[i] += first;
         hi[i] += first;
-        if (hi[i] > lo[i]) PSA_TRY(psa_search_async(g->ctx[i], lo[i], hi[i]));
-    }
-    for (int i = 0; i < ndev; ++i) {
-        psa_result r;
-        r.score = g->is_max ? -INFINITY : INFINITY;          // an empty shard: "nothing found" (cuda_funcs.cu:158-161)
-        r.offset = -1; r.char_offset = -1; r.ch = 0; r.pairs = 0;
-        if (hi[i] > lo[i]) PSA_TRY(psa_search_wait(g->ctx[i], &r));
-        r.shard = i;
-        g->h_send[i] = r;
-    }
-    // the exchange: every device contributes its record, every device ends up with all of them
-    for (int i = 0; i < ndev; ++i) {
-        PSA_HIP(hipSetDevice(g->devices[i]));
-        PSA_HIP(hipMemcpyAsync(g->d_send[i], &g->h_send[i], sizeof(psa_result), hipMemcpyHostToDevice, g->ctx[i]->stream));
-    }
-    PSA_NCCL(g_rccl.group_start());
-    for (int i = 0; i < ndev; ++i)
-        PSA_NCCL(g_rccl.all_gather(g->d_send[i], g->d_recv[i], sizeof(psa_result), ncclChar, g->comm[i], g->ctx[i]->stream));
-    PSA_NCCL(g_rccl.group_end());
-    for (int i = 0; i < ndev; ++i) {
-        PSA_HIP(hipSetDevice(g->devices[i]));
-        PSA_HIP(hipMemcpyAsync(g->h_recv + (size_t)i * ndev, g->d_recv[i], sizeof(psa_result) * (size_t)ndev,
-                               hipMemcpyDeviceToHost, g->ctx[i]->stream));
-    }
-    for (int i = 0; i < ndev; ++i) {
-        PSA_HIP(hipSetDevice(g->devices[i]));
-        PSA_HIP(hipStreamSynchronize(g->ctx[i]->stream));
-    }
-    // every "rank" folds the same records (checked: the gathered sets are identical)
-    for (int i = 1; i < ndev; ++i)
-        if (std::memcmp(g->h_recv, g->h_recv + (size_t)i * ndev, sizeof(psa_result) * (size_t)ndev) != 0) {
-            set_last_error("internal: the devices disagree about the exchanged records");
-            return PSA_ERR_DEVICE;
+        // what the record must carry in `shard` to count as this search's: the shard and the search's number
+        tag[i] = i | (((c->seq + 1) & 0x3fffff) << 8);
+        if (hi[i] > lo[i]) {
+            PSA_TRY(search_async_impl(c, lo[i], hi[i], g->d_send[i], tag[i]));
+        } else {
+            psa_result r;                                    // an empty shard: "nothing found" (cuda_funcs.cu:158-161)
+            r.score = g->is_max ? -INFINITY : INFINITY;
+            r.offset = -1; r.char_offset = -1; r.ch = 0; r.pairs = 0;
+            r.shard = tag[i];
+            g->h_send[i] = r;
+            c->seq += 1;
+            PSA_TRY(ensure_device(c));
+            PSA_HIP(hipMemcpyAsync(g->d_send[i], &g->h_send[i], sizeof(psa_result), hipMemcpyHostToDevice, c->stream));
         }
+    }
+    // the exchange: every device contributes its record
+    if (g->exchange == PSA_EXCHANGE_RCCL) {
+        PSA_NCCL(g_rccl.group_start());
+        for (int i = 0; i < ndev; ++i)
+            PSA_NCCL(g_rccl.all_gather(g->d_send[i], g->d_recv[i], sizeof(psa_result), ncclChar, g->comm[i], g->ctx[i]->stream));
+        PSA_NCCL(g_rccl.group_end());
+        PSA_TRY(ensure_device(g->ctx[0]));
+        PSA_HIP(hipMemcpyAsync(g->h_recv, g->d_recv[0], sizeof(psa_result) * (size_t)ndev, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+        PSA_HIP(hipStreamSynchronize(g->ctx[0]->stream));       // device 0 holds every record: every search has ended
+    } else {
+        for (int i = 0; i < ndev; ++i) {
+            PSA_TRY(ensure_device(g->ctx[i]));
+            PSA_HIP(hipMemcpyAsync(g->h_recv + i, g->d_send[i], sizeof(psa_result), hipMemcpyDeviceToHost, g->ctx[i]->stream));
+        }
+        for (int i = 0; i < ndev; ++i) {
+            PSA_TRY(ensure_device(g->ctx[i]));
+            PSA_HIP(hipStreamSynchronize(g->ctx[i]->stream));
+        }
+    }
+    psa_status st = PSA_OK;
+    for (int i = 0; i < ndev; ++i) {
+        psa_context* c = g->ctx[i];
+        if (c->pending && st == PSA_OK && g->h_recv[i].shard != tag[i]) {
+            // this device's search asks for the host (or its record is not this search's): the single-context path
+            st = ensure_device(c);
+            if (st == PSA_OK && hipStreamSynchronize(c->stream) != hipSuccess) {
+                set_last_error("psa_search_sharded: stream synchronisation failed");
+                st = PSA_ERR_DEVICE;
+            }
+            if (st == PSA_OK) st = settle_search(c);
+            if (st == PSA_OK) g->h_recv[i] = c->h_tails[0].result;
+        } else if (c->pending && c->pending_filter) {
+            c->slot[0].scal_dirty = false;               // its last workgroup zeroed the search scalars
+        }
+        c->pending = false;
+        c->record_out = nullptr;
+        c->record_shard = -1;
+        g->h_recv[i].shard = i;
+    }
+    PSA_TRY(st);
     if (shard_records) std::memcpy(shard_records, g->h_recv, sizeof(psa_result) * (size_t)ndev);
     return psa_fold(g->h_recv, ndev, g->is_max, out);
 }
 
 
 // A batch of queries over the group (BASELINE.json configs[4] on several GPUs): the queries are dealt to the devices
-// in contiguous blocks (the last device takes the remainder, as cpu_funcs.c:128-133 deals offsets), every device runs
-// its block through psa_search_batch / _minmax on its own host thread (the calls block), then ONE RCCL all-gather
-// leaves all records on every device and the host copies device 0's set.  results_min == NULL: one mode (the group's).
+// in contiguous blocks (psa_query_block: as even as possible), every device runs its block through psa_search_batch /
+// _minmax on its own host thread (the calls block), then ONE RCCL all-gather leaves all records on every device and
+// the host copies device 0's set (psa_batch_unpack puts them in query order).  results_min == NULL: one mode (the group's).
 psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, int m, size_t stride,
                                     int first, int last, psa_result* results, psa_result* results_min)
 {
@@ -2075,9 +2289,10 @@ psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, i
         return PSA_ERR_ARG;
     }
     if (!g->have_weights || g->n < 0) { set_last_error("weights and seq1 must be set before a search"); return PSA_ERR_STATE; }
+    DeviceScope device_scope;
     const int ndev = (int)g->ctx.size();
     const int nmodes = results_min ? 2 : 1;
-    const int per = (nq + ndev - 1) / ndev;                 // records per device and mode in the exchange (padded)
+    const int per = psa_query_block_max(nq, ndev);          // records per device and mode in the exchange (the largest block)
     if (per > g->batch_per) {
         for (size_t i = 0; i < g->d_bsend.size(); ++i) {
             PSA_HIP(hipSetDevice(g->devices[i]));
@@ -2099,8 +2314,7 @@ psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, i
         PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_brecv), sizeof(psa_result) * 2 * (size_t)per * ndev, hipHostMallocPortable));
         g->batch_per = per;
     }
-    // the devices' blocks: device i searches queries [lo_i, hi_i)
-    const int base = nq / ndev;
+    // the devices' blocks: device i searches queries [lo_i, hi_i) and fills block i of the exchange, [mode][per]
     std::vector<int> lo((size_t)ndev), hi((size_t)ndev);
     std::vector<psa_status> status((size_t)ndev, PSA_OK);
     std::vector<std::string> errors((size_t)ndev);
@@ -2108,14 +2322,14 @@ psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, i
     psa_result none;
     none.score = 0.0; none.offset = -1; none.char_offset = -1; none.ch = 0; none.shard = -1; none.pairs = 0;
     for (int i = 0; i < ndev; ++i) {
-        lo[i] = base * i;
-        hi[i] = i == ndev - 1 ? nq : lo[i] + base;
-        psa_result* mine = g->h_bsend + (size_t)i * 2 * per;          // [mode][per]
+        psa_query_block(nq, ndev, i, &lo[i], &hi[i]);
+        psa_result* mine = g->h_bsend + (size_t)i * 2 * per;
         for (int k = 0; k < 2 * per; ++k) mine[k] = none;
-        if (hi[i] <= lo[i]) continue;
+        const int count = hi[i] - lo[i];
+        if (count <= 0) continue;
+        if (count > per) { set_last_error("internal: a query block exceeds the exchange block"); return PSA_ERR_STATE; }
         workers.emplace_back([=, &status, &errors]() {
             const char* q0 = queries + (size_t)lo[i] * stride;
-            const int count = hi[i] - lo[i];
             psa_status st;
             if (nmodes == 2) {
                 // the group's mode first: results / results_min are MAX / MIN
@@ -2134,31 +2348,25 @@ psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, i
         if (status[i] != PSA_OK) { set_last_error(errors[i]); return status[i]; }
     // the exchange: one all-gather of the per-device blocks
     const size_t block = sizeof(psa_result) * 2 * (size_t)per;
-    for (int i = 0; i < ndev; ++i) {
-        PSA_HIP(hipSetDevice(g->devices[i]));
-        PSA_HIP(hipMemcpyAsync(g->d_bsend[i], g->h_bsend + (size_t)i * 2 * per, block, hipMemcpyHostToDevice, g->ctx[i]->stream));
-    }
-    PSA_NCCL(g_rccl.group_start());
-    for (int i = 0; i < ndev; ++i)
-        PSA_NCCL(g_rccl.all_gather(g->d_bsend[i], g->d_brecv[i], block, ncclChar, g->comm[i], g->ctx[i]->stream));
-    PSA_NCCL(g_rccl.group_end());
-    PSA_HIP(hipSetDevice(g->devices[0]));
-    PSA_HIP(hipMemcpyAsync(g->h_brecv, g->d_brecv[0], block * (size_t)ndev, hipMemcpyDeviceToHost, g->ctx[0]->stream));
-    for (int i = 0; i < ndev; ++i) {
-        PSA_HIP(hipSetDevice(g->devices[i]));
-        PSA_HIP(hipStreamSynchronize(g->ctx[i]->stream));
-    }
-    for (int i = 0; i < ndev; ++i)
-        for (int q = lo[i]; q < hi[i]; ++q) {
-            const psa_result* blockp = g->h_brecv + (size_t)i * 2 * per;
-            results[q] = blockp[q - lo[i]];
-            results[q].shard = q;
-            if (results_min) {
-                results_min[q] = blockp[per + (q - lo[i])];
-                results_min[q].shard = q;
-            }
+    const psa_result* gathered = g->h_bsend;                // host exchange: the blocks already lie side by side
+    if (g->exchange == PSA_EXCHANGE_RCCL) {
+        for (int i = 0; i < ndev; ++i) {
+            PSA_HIP(hipSetDevice(g->devices[i]));
+            PSA_HIP(hipMemcpyAsync(g->d_bsend[i], g->h_bsend + (size_t)i * 2 * per, block, hipMemcpyHostToDevice, g->ctx[i]->stream));
         }
-    return PSA_OK;
+        PSA_NCCL(g_rccl.group_start());
+        for (int i = 0; i < ndev; ++i)
+            PSA_NCCL(g_rccl.all_gather(g->d_bsend[i], g->d_brecv[i], block, ncclChar, g->comm[i], g->ctx[i]->stream));
+        PSA_NCCL(g_rccl.group_end());
+        PSA_HIP(hipSetDevice(g->devices[0]));
+        PSA_HIP(hipMemcpyAsync(g->h_brecv, g->d_brecv[0], block * (size_t)ndev, hipMemcpyDeviceToHost, g->ctx[0]->stream));
+        for (int i = 0; i < ndev; ++i) {
+            PSA_HIP(hipSetDevice(g->devices[i]));
+            PSA_HIP(hipStreamSynchronize(g->ctx[i]->stream));
+        }
+        gathered = g->h_brecv;
+    }
+    return psa_batch_unpack(gathered, nq, ndev, results, results_min);
 }
 }  // extern "C"
 
@@ -2196,7 +2404,22 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
     returned_mutant->char_offset = -1;
     returned_mutant->ch = PSA_NO_CHAR;
     const double none = is_max ? -INFINITY : INFINITY;
+    // A plain symbol cannot see how its caller compiled ProgramData.  What a mismatch looks like from here: no NUL
+    // inside an array, or an empty Seq2 (the caller's seq2 lies elsewhere).  Say so instead of answering from the
+    // wrong bytes (the reference prints and exits on every error, cuda_funcs.cu:44-48).
+    if ((size_t)n >= seq1_cap || (size_t)m >= seq2_cap) {
+        std::fprintf(stderr, "gpu_run_program: no NUL inside seq1[%zu] / seq2[%zu] - the caller's ProgramData was compiled with "
+                             "other array limits than this entry point reads (the plain symbol reads the reference's stock "
+                             "10001 / 5001 layout; other limits: gpu_run_program_layout, or include psa.h)\n", seq1_cap, seq2_cap);
+        std::exit(EXIT_FAILURE);
+    }
+    if (m < 1 && n >= 1 && last_offset > first_offset) {
+        std::fprintf(stderr, "gpu_run_program: seq2 is empty at offset %zu of ProgramData - if the caller was compiled with array "
+                             "limits other than %zu / %zu its seq2 lies elsewhere (use gpu_run_program_layout, or include psa.h); "
+                             "nothing searched\n", (size_t)40 + seq1_cap, seq1_cap, seq2_cap);
+    }
     if (m < 1 || last_offset <= first_offset) return none;
+    DeviceScope device_scope;
 
     // PSA_DEVICES=0,1,...: the offsets are sharded over those GPUs (psa_search_sharded: the reference's MPI
     // ranks, cpu_funcs.c:49-94, as one process and one RCCL exchange); otherwise one GPU, PSA_DEVICE (default 0)
@@ -2214,7 +2437,11 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
     psa_result r;
     if (devices.size() > 1) {
         if (n < 1) legacy_die("Failed to copy data from host to device (seq1)");
-        if (!g_legacy_group && psa_group_create(devices.data(), (int)devices.size(), &g_legacy_group) != PSA_OK)
+        // PSA_EXCHANGE=host: the records meet in host memory instead of an RCCL all-gather (a device may then be listed
+        // more than once: an N-way split rehearsed on fewer GPUs)
+        const char* ex = std::getenv("PSA_EXCHANGE");
+        const int exchange = ex && std::strcmp(ex, "host") == 0 ? PSA_EXCHANGE_HOST : PSA_EXCHANGE_RCCL;
+        if (!g_legacy_group && psa_group_create_ex(devices.data(), (int)devices.size(), exchange, &g_legacy_group) != PSA_OK)
             legacy_die("Failed to initialise the device group (PSA_DEVICES)");
         psa_group* g = g_legacy_group;
         if (psa_group_set_weights(g, weights, is_max) != PSA_OK) legacy_die("Failed to build the score tables");
@@ -2230,12 +2457,12 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
         }
         psa_context* c = g_legacy_ctx;
         if (psa_set_weights(c, weights, is_max) != PSA_OK) legacy_die("Failed to build the score tables");
-        // Both sequences go through the one staging buffer in stream order (copy, encode, copy, encode) and the
-        // call synchronises once, at the end of the search: the alphabet flag comes back with the result tail.
-        if (n < 1 || ensure_device(c) != PSA_OK || stage_host(c, seq1, (size_t)n) != PSA_OK || encode_seq1(c, c->d_raw, n) != PSA_OK)
-            legacy_die("Failed to copy data from host to device (seq1)");
-        if (stage_host(c, seq2, (size_t)m) != PSA_OK || encode_seq2(c, c->slot[0], c->d_raw, m, c->stream) != PSA_OK)
-            legacy_die("Failed to copy data from host to device (seq2)");
+        // The two arrays of a ProgramData lie side by side: one copy command (the reference copies the whole struct,
+        // cuda_funcs.cu:50), one encode launch, one search launch, and the call synchronises once, at the end of the
+        // search: the alphabet flag comes back with the result tail.
+        if (n < 1 || ensure_device(c) != PSA_OK || stage_host_pair(c, seq1, (size_t)n, seq2, (size_t)m) != PSA_OK ||
+            encode_pair(c, c->d_raw, n, c->d_raw + c->raw_second, m) != PSA_OK)
+            legacy_die("Failed to copy data from host to device");
         if (psa_search(c, first_offset, last_offset, &r) != PSA_OK) legacy_die("Failed to run the search");
     }
     if (r.offset < 0 || r.ch == 0) return none;   // cuda_funcs.cu:143-144
@@ -2249,6 +2476,18 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
 // that is what an unmodified reference build passes.  Callers built with other limits use
 // gpu_run_program_layout (psa.h does it for them).
 double gpu_run_program(const ProgramData* cpu_data, Mutant* returned_mutant, int first_offset, int last_offset)
+{
+    return gpu_run_program_layout(cpu_data, PSA_REF_SEQ1_MAX_LEN, PSA_REF_SEQ2_MAX_LEN, returned_mutant,
+                                  first_offset, last_offset);
+}
+
+// The reference compiles every file as C++ (Makefile:9-12) and declares no extern "C": its cpu_funcs.o refers to
+// gpu_run_program(ProgramData*, Mutant*, int, int) by its Itanium-mangled name (cuda_funcs.h:33, call site
+// cpu_funcs.c:180; the struct tags are _data and _mutant, program_data.h:6, mutant.h:6).  The same entry under
+// that name: an unmodified reference object links without an edit.
+PSA_EXPORT double psa_gpu_run_program_cxx(ProgramData* cpu_data, Mutant* returned_mutant, int first_offset, int last_offset)
+    __asm__("_Z15gpu_run_programP5_dataP7_mutantii");
+double psa_gpu_run_program_cxx(ProgramData* cpu_data, Mutant* returned_mutant, int first_offset, int last_offset)
 {
     return gpu_run_program_layout(cpu_data, PSA_REF_SEQ1_MAX_LEN, PSA_REF_SEQ2_MAX_LEN, returned_mutant,
                                   first_offset, last_offset);

@@ -183,9 +183,8 @@ struct PrepareArgs {
     int                  nslots;
 };
 
-__global__ __launch_bounds__(256) void psa_prepare_seq1_kernel(PrepareArgs a)
+__device__ __forceinline__ void prepare_seq1_slot(const PrepareArgs& a, int slot)
 {
-    const int slot = blockIdx.x * 256 + threadIdx.x;
     if (slot >= a.nslots) return;
     const int p0 = slot * 32;
     unsigned w[8];
@@ -219,6 +218,49 @@ __global__ __launch_bounds__(256) void psa_prepare_seq1_kernel(PrepareArgs a)
     uint4* dst = reinterpret_cast<uint4*>(a.codes + p0);
     dst[0] = make_uint4(cw[0], cw[1], cw[2], cw[3]);
     dst[1] = make_uint4(cw[4], cw[5], cw[6], cw[7]);
+}
+
+__global__ __launch_bounds__(256) void psa_prepare_seq1_kernel(PrepareArgs a)
+{
+    prepare_seq1_slot(a, blockIdx.x * 256 + threadIdx.x);
+}
+
+// ---- Seq2 of a single search: ASCII -> the three encodings the engines read ----------
+struct Seq2Args {
+    const unsigned char* raw;       // ASCII (device), m bytes
+    unsigned int*        rows;      // [capacity] code << kRowShift, natural order (sequential engine: scalar loads)
+    unsigned char*       bytes;     // [capacity] codes (re-score)
+    unsigned int*        classes;   // code << kRowShift in the count kernels' class order (class_index)
+    int*                 bad;
+    int m, capacity;
+    int class_chars, class_total;   // the chunking the class order is laid out for
+};
+
+__device__ __forceinline__ void encode_seq2_char(const Seq2Args& a, int i)
+{
+    if (i >= a.capacity) return;
+    int code = kCodePad;
+    if (i < a.m) {
+        const unsigned char c = a.raw[i];
+        code = (c >= 'A' && c <= 'Z') ? c - 'A' : (c == '-' ? kCodeHyphen : kCodeBad);
+        if (code == kCodeBad) { atomicOr(a.bad, 2); code = kCodePad; }
+    }
+    a.rows[i] = (unsigned int)code << kRowShift;    // symbol as a 4 KiB row offset; the sequential engine
+    a.bytes[i] = (unsigned char)code;               // shifts it back to a table row
+    if (i < a.class_total) a.classes[class_index(i, a.class_chars)] = (unsigned int)code << kRowShift;
+    else if (i < a.class_total + kUnroll) a.classes[i] = (unsigned int)kCodePad << kRowShift;
+}
+
+__global__ __launch_bounds__(256) void psa_encode_seq2_kernel(Seq2Args a)
+{
+    encode_seq2_char(a, blockIdx.x * 256 + threadIdx.x);
+}
+
+// both sequences of a search in ONE launch (psa_set_sequences*, gpu_run_program): blocks [0, blocks1) take Seq1
+__global__ __launch_bounds__(256) void psa_encode_pair_kernel(PrepareArgs a1, Seq2Args a2, int blocks1)
+{
+    if ((int)blockIdx.x < blocks1) prepare_seq1_slot(a1, blockIdx.x * 256 + threadIdx.x);
+    else encode_seq2_char(a2, ((int)blockIdx.x - blocks1) * 256 + threadIdx.x);
 }
 
 // out[b] bit t = in[t] bit b  (recursive block swap, Hacker's Delight 7-3, mirrored)
@@ -530,6 +572,454 @@ __device__ __forceinline__ double thread_bounds(const BoundParams& b, const unsi
     return pess;
 }
 
+// ---- rescore: the reference's sequential fp64 sum for each candidate -----------
+// One wave per candidate.  The additions of cpu_funcs.c:278 are a serial chain of
+// m roundings, but while the running sum stays inside one binade every addend is
+// rounded to that binade's ulp, i.e. the chain is an INTEGER walk in units of the
+// ulp:  S += R_e[class]  with R_e[c] = round(p_c / ulp_e).  Integer adds commute,
+// so a batch of 512 chars is summed with a wave-wide prefix scan and accepted when
+// every prefix stays strictly inside the binade (then each partial sum is provably
+// the reference's, see DESIGN.md "exact fast path"); the char that leaves the
+// binade, binades where an addend falls exactly between two grid points (a
+// round-half-even tie) and the first chars (|sum| comparable to the addends) run
+// the plain chain of v_add_f64.
+struct CandRec {                    // one re-scored candidate
+    double score;                   // exact total + best delta
+    int    offset;
+    int    char_offset;             // first char with the best delta rank
+    int    rank;                    // 0 = no substitution possible
+    int    ch;                      // substituted character
+};
+
+struct RescoreArgs {
+    const unsigned char* s1;
+    const unsigned char* s2;        // byte codes
+    const unsigned char* clsrank;   // [32][32]: class (bits 0-2) | delta rank (bits 3-7), [c2][c1]
+    const unsigned char* sub;       // [32][32]
+    const double*        delta_of_rank;
+    const int*           cand;
+    const double*        cand_upper;  // optimistic bounds of the candidates, or NULL (already filtered)
+    unsigned long long*  global_best; // final best pessimistic bound (ordered-u64)
+    int*                 cand_count;
+    CandRec*             rec;       // [cap]
+    int*                 done;      // arrival counter of the candidate workgroups
+    SearchTail*          out;       // written by the last workgroup to arrive
+    const int*           bad;       // the encode kernels' alphabet flag
+    long long            pairs;
+    int                  seq;       // sequence number of the search, echoed in the tail
+    double class_value[8];          // pair score of class 0..3, +0.0 for the padding class 4
+    int m;
+    int cap;
+    int is_max;
+    int fast_ok;                    // all weights normal doubles or zero
+    int fast_min_exp;               // smallest biased exponent of the running sum the walk handles
+    // blockIdx.y = query of a batch launch: its state lies query_stride... further on (all 0 for one search)
+    size_t s2_stride;               // bytes between the queries' codes
+    int    batched;                 // 1: cand/cand_upper/rec advance by cap, the scalars by kScalStride, out and seq by 1
+    // single searches of a device group: the 32-byte record also goes to device memory (what the devices exchange)
+    psa_result* record_out;         // or NULL
+    int         record_shard;
+};
+
+#ifndef PSA_RESCORE_EPL
+#define PSA_RESCORE_EPL 8
+#endif
+constexpr int kRescoreEpl = PSA_RESCORE_EPL;   // chars per lane and batch on the integer walk
+constexpr int kRescoreThreads = 512;
+constexpr int kRescoreChunk = 32768;    // chars whose class codes are staged in LDS at a time
+constexpr int kRescoreGrid = 64;        // workgroups; each takes candidates ci = block, block + 64, ...
+constexpr int kRescorePadLds = 36 * 1024;   // + ~35 KB static: a rescore and a count workgroup never share a CU
+
+// Inclusive prefix sum of a 64-bit value over the 64 lanes, by DPP row shifts and row
+// broadcasts (register-to-register; no LDS round trips as __shfl_up would need).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ long long dpp_add(long long v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    return v + (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ long long wave_scan_inclusive(long long v)
+{
+    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> inclusive scan inside each row of 16 lanes
+    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
+__device__ __forceinline__ long long readlane64(long long v, int l)
+{
+    const unsigned lo = __builtin_amdgcn_readlane((int)v, l);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+
+// ---- building blocks shared by psa_rescore_kernel and the fused tail of psa_count_kernel ----
+// Class | rank codes of chars [c0, c1) of one candidate (Seq1 window s1 = codes of Seq1 from the candidate's
+// offset) into LDS, chunk-relative, four chars per thread and step; positions from c1 up to the walk's
+// over-read are padding (class 4, addend +0.0).  `key` collects max(rank << 32 | ~i): best delta rank, then
+// the lowest char index (cpu_funcs.c:287-294: strict compare keeps the first i).
+__device__ __forceinline__ void classify_chars(const unsigned char* __restrict__ s1, const unsigned char* __restrict__ s2,
+                                               const unsigned char* s_clsrank, unsigned char* s_codes, int c0, int c1,
+                                               int tid, int nthreads, unsigned long long& key)
+{
+    const int groups = (c1 - c0 + 64 * kRescoreEpl + 3) >> 2;
+#pragma unroll 4
+    for (int g = tid; g < groups; g += nthreads) {
+        const int i = c0 + 4 * g;                         // c0 and the Seq2 code buffer are 4-byte aligned
+        const unsigned w2 = *reinterpret_cast<const unsigned*>(s2 + i);   // both buffers are padded with
+        unsigned w1;                                                         // kCodePad (class 4, rank 0)
+        __builtin_memcpy(&w1, s1 + i, 4);
+        unsigned packed = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned cr = 4u;
+            if (i + j < c1) {
+                cr = s_clsrank[((w2 >> (8 * j)) & 0xffu) * kRow + ((w1 >> (8 * j)) & 0xffu)];
+                const unsigned long long k2 = ((unsigned long long)(cr >> 3) << 32) | (0xffffffffu - (unsigned)(i + j));
+                key = k2 > key ? k2 : key;
+            }
+            packed |= cr << (8 * j);
+        }
+        *reinterpret_cast<unsigned*>(s_codes + 4 * g) = packed;
+    }
+}
+
+struct WalkScratch {                // per walking wave, in LDS
+    double    vals[64];
+    long long round[8];
+};
+struct WalkStats { int chain, batches, left; };     // how a walk went (phase-timing builds print them)
+
+// The reference's sum over chars [c0, c1) continued from `s` (cpu_funcs.c:278), by ONE wave (all 64 lanes call
+// this with the same arguments); s_codes = the chars' class codes from classify_chars (index k - c0), s_class =
+// the class values.  Returns the new running sum, bit for bit what the m sequential fp64 additions give.
+__device__ __forceinline__ double walk_sum(double s, const unsigned char* s_codes, int c0, int c1, const double* s_class,
+                                           WalkScratch* ws, int fast_ok, int fast_min_exp, int lane, WalkStats& st)
+{
+    int k = c0;
+    while (k < c1) {
+        const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
+        const int e = (int)((sb >> 52) & 0x7ff);
+        bool walk = fast_ok && e >= fast_min_exp && e < 0x7ff;
+        if (walk) {
+            // R_e[c] for the five classes, and whether any addend ties in this binade
+            long long r = 0;
+            bool tie = false;
+            if (lane < 5) {
+                const unsigned long long pb = (unsigned long long)__double_as_longlong(s_class[lane]);
+                const int ep = (int)((pb >> 52) & 0x7ff);
+                if (ep != 0) {                           // zero stays 0 (subnormals excluded by fast_ok)
+                    const unsigned long long mp = (pb & 0xfffffffffffffull) | (1ull << 52);
+                    const int d = e - ep;                // >= 2 by fast_min_exp
+                    if (d <= 53) {
+                        const unsigned long long half = 1ull << (d - 1);
+                        tie = (mp & ((half << 1) - 1)) == half;
+                        const long long mag = (long long)((mp + half) >> d);
+                        r = (pb >> 63) ? -mag : mag;
+                    }
+                }
+                ws->round[lane] = r;
+            }
+            if (__ballot(tie) != 0ull) walk = false;
+        }
+        if (!walk) {
+            ++st.chain;
+            // plain chain over the next <= 64 chars; lanes past the chunk hold +0.0 (exact to add)
+            const int nb = c1 - k < 64 ? c1 - k : 64;
+            ws->vals[lane] = lane < nb ? s_class[s_codes[k - c0 + lane] & 7u] : 0.0;
+            __builtin_amdgcn_wave_barrier();
+            const double2* v = reinterpret_cast<const double2*>(ws->vals);   // same address in every lane: broadcast
+#pragma unroll
+            for (int l = 0; l < 32; ++l) {
+                const double2 x = v[l];
+                s += x.x;                                 // reference order (cpu_funcs.c:278)
+                s += x.y;
+            }
+            __builtin_amdgcn_wave_barrier();
+            k += nb;
+            continue;
+        }
+        // integer walk inside binade e
+        __builtin_amdgcn_wave_barrier();
+        long long S = (long long)((sb & 0xfffffffffffffull) | (1ull << 52));
+        const bool neg = (sb >> 63) != 0;
+        if (neg) S = -S;
+        // |q| strictly inside (2^52, 2^53)  <=>  q strictly inside (bound_lo, bound_hi)
+        const long long bound_lo = neg ? -(1ll << 53) : (1ll << 52);
+        const long long bound_hi = neg ? -(1ll << 52) : (1ll << 53);
+        static_assert(kRescoreEpl % 8 == 0 && kRescoreEpl <= 16, "a lane's codes of one batch are 8-byte LDS words");
+        constexpr int kWords = kRescoreEpl / 8;
+        bool left = false;
+        while (k < c1 && !left) {
+            // The batch starts at the kRescoreEpl-aligned position at or below k; chars below k are already
+            // in S and count as padding (class 4, addend 0), like the staged positions past c1.
+            const int k_al = k & ~(kRescoreEpl - 1);
+            unsigned long long w[kWords];
+#pragma unroll
+            for (int x = 0; x < kWords; ++x)
+                w[x] = *reinterpret_cast<const unsigned long long*>(s_codes + (k_al - c0) + lane * kRescoreEpl + 8 * x);
+            if (lane == 0 && k != k_al) {
+#pragma unroll
+                for (int x = 0; x < kWords; ++x) {
+                    const int skip = k - k_al - 8 * x;                  // chars of this word already summed
+                    if (skip >= 8) w[x] = 0x0404040404040404ull;
+                    else if (skip > 0) {
+                        const unsigned long long keep = ~0ull << (8 * skip);
+                        w[x] = (w[x] & keep) | (0x0404040404040404ull & ~keep);
+                    }
+                }
+            }
+            long long rr[kRescoreEpl];
+            long long t = 0;
+#pragma unroll
+            for (int j = 0; j < kRescoreEpl; ++j) {
+                rr[j] = ws->round[(unsigned)(w[j >> 3] >> (8 * (j & 7))) & 7u];
+                t += rr[j];
+            }
+            ++st.batches;
+            const long long incl = wave_scan_inclusive(t);
+            const long long q0 = S + (incl - t);          // sum before this lane's first char
+            long long q = q0;
+            bool inside = true;
+#pragma unroll
+            for (int j = 0; j < kRescoreEpl; ++j) {
+                q += rr[j];
+                inside &= (q > bound_lo) & (q < bound_hi);
+            }
+            const unsigned long long bad_lanes = __ballot(!inside);
+            if (bad_lanes == 0ull) {
+                S = readlane64(q, 63);
+                k = k_al + 64 * kRescoreEpl < c1 ? k_al + 64 * kRescoreEpl : c1;
+            } else {
+                // rare (once per binade change): find the first char that leaves the binade
+                int bad = kRescoreEpl;
+                long long prev = q0, run = q0;
+#pragma unroll
+                for (int j = 0; j < kRescoreEpl; ++j) {
+                    const long long nxt = run + rr[j];
+                    if (!((nxt > bound_lo) & (nxt < bound_hi)) && bad == kRescoreEpl) { bad = j; prev = run; }
+                    run = nxt;
+                }
+                const int L = __ffsll((long long)bad_lanes) - 1;
+                const int j = __builtin_amdgcn_readlane(bad, L);
+                S = readlane64(prev, L);                  // the sum before the char that leaves the binade
+                const int p = k_al + L * kRescoreEpl + j;
+                k = p > k ? p : k;                        // (a skipped char can only "fail" with S on the binade's edge)
+                left = true;
+            }
+        }
+        const unsigned long long mag = (unsigned long long)(S < 0 ? -S : S);
+        s = __longlong_as_double((long long)((neg ? (1ull << 63) : 0ull) | ((unsigned long long)e << 52) |
+                                             (mag & 0xfffffffffffffull)));
+        if (left) {
+            ++st.left;
+            // this char moves the sum out of the binade: one true fp64 add
+            s += s_class[s_codes[k - c0] & 7u];
+            k += 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return s;
+}
+
+// is_swapable (cuda_funcs.cu:290-307) over re-scored candidates; rank 0 = "no substitution possible": never wins
+__device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const CandRec* best, int status)
+{
+    const bool is_max = a.is_max != 0;
+    psa_result r;
+    if (best) {
+        r.score = best->score;
+        r.offset = best->offset;
+        r.char_offset = best->char_offset;
+        r.ch = best->ch;
+    } else {
+        r.score = status ? 0.0 : (is_max ? -INFINITY : INFINITY);
+        r.offset = -1;
+        r.char_offset = -1;
+        r.ch = 0;
+    }
+    r.shard = -1;
+    r.pairs = a.pairs;
+    a.out->result = r;
+    a.out->bad = *a.bad;
+    a.out->overflow = status;
+    a.out->seq = a.seq;
+    if (a.record_out) {
+        // the record a device group exchanges: shard = the shard's index, or -2 - status when the host has to look
+        // at this search again (candidate list overflow, separate re-score launch)
+        r.shard = status ? -2 - status : a.record_shard;
+        *a.record_out = r;
+    }
+}
+
+// ---- values other workgroups wrote / will read inside the same launch ----------------
+// Write-through (sc1) stores and agent-scope loads: they pass the XCD's L2, so the hand-off needs no L2 write-back
+// (MI355X_MICROARCH.md, "Valid forms": every storing wave drains its stores, workgroup barrier, ONE lane's arrival).
+__device__ __forceinline__ void store_agent(int* p, int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_agent(double* p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int load_agent(const int* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long load_agent(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double* p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+// ---- end of a single search inside the count kernel ---------------------------------
+// Run by the last tile workgroup to arrive (all of its waves).  The candidate list is complete and the bound in
+// global_best final: candidates it rules out are dropped, the survivors (a handful) are re-scored in the reference's
+// summation order — every wave of the workgroup classifies, then one wave per candidate walks — folded in the
+// is_swapable order and the tail is written.  More survivors than waves, or a Seq2 whose codes do not fit the LDS:
+// status 2, the host launches psa_rescore_kernel on the untouched lists.
+constexpr int kFusedMax = 16;
+constexpr int kFusedWaves = 16;
+// LDS in front of the candidates' class codes (finish_search's carve-up) and how many candidates' codes fit at a time
+constexpr int kFusedFixedBytes = kRow * kRow + 8 * (int)sizeof(double) + kFusedWaves * (int)sizeof(WalkScratch) +
+                                 kFusedMax * kFusedWaves * 8 + kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4 + 16;
+__host__ __device__ inline int fused_candidates_at_a_time(int lds_bytes, int m)
+{
+    const int region = (m + 64 * kRescoreEpl + 16 + 15) & ~15;       // one candidate's codes + the walk's over-read
+    const int g = (lds_bytes - kFusedFixedBytes) / region;
+    return g > kFusedWaves ? kFusedWaves : g;
+}
+
+template <int WAVES>
+__device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned char* lds, int lds_bytes, int tid)
+{
+    static_assert(WAVES <= kFusedMax, "one walking wave per survivor of a round");
+    static_assert(sizeof(WalkScratch) % 16 == 0 && sizeof(CandRec) == 24, "LDS carve-up below");
+    constexpr int T = WAVES * 64;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char* p = lds;
+    unsigned char* s_clsrank = p;                                             p += kRow * kRow;
+    double* s_class = reinterpret_cast<double*>(p);                           p += 8 * sizeof(double);
+    WalkScratch* s_walk = reinterpret_cast<WalkScratch*>(p);                  p += WAVES * sizeof(WalkScratch);
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(p);    p += kFusedMax * WAVES * 8;   // [candidate of the round][wave]
+    CandRec* s_rec = reinterpret_cast<CandRec*>(p);                           p += kFusedMax * sizeof(CandRec);
+    int* s_surv = reinterpret_cast<int*>(p);                                  p += kFusedMax * 4;
+    int* s_n = reinterpret_cast<int*>(p);                                     p += 16;
+    unsigned char* s_codes = p;
+    const int m = r.m;
+    const int region = (m + 64 * kRescoreEpl + 16 + 15) & ~15;               // codes of one candidate + the walk's over-read
+    static_assert(WAVES == kFusedWaves, "kFusedFixedBytes is this carve-up for 16 waves");
+    const int G = fused_candidates_at_a_time(lds_bytes, m);                  // candidates classified at a time
+
+    const int count = load_agent(r.cand_count);
+    if (count > r.cap) {
+        // overflow against the running bound: the bound stays in global_best, the host selects once more against it
+        if (tid == 0) {
+            write_search_tail(r, nullptr, 1);
+            store_agent(r.cand_count, 0);
+            store_agent(r.done, 0);
+        }
+        return;
+    }
+    for (int k = tid; k < kRow * kRow; k += T) s_clsrank[k] = r.clsrank[k];
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_class[k] = r.class_value[k];
+        s_n[0] = 0;
+    }
+    __syncthreads();
+    const double final_best = key_order(load_agent(r.global_best));
+    for (int ci = tid; ci < count; ci += T)
+        if (load_agent(r.cand_upper + ci) >= final_best) {
+            const int k = atomicAdd(&s_n[0], 1);
+            if (k < kFusedMax) s_surv[k] = load_agent(r.cand + ci);
+        }
+    __syncthreads();
+    const int nsurv = s_n[0];
+    if (nsurv > kFusedMax || G < 1) {
+        if (tid == 0) {
+            write_search_tail(r, nullptr, 2);
+            store_agent(r.done, 0);                      // psa_rescore_kernel counts its own arrivals in it
+        }
+        return;
+    }
+    for (int base = 0; base < nsurv; base += G) {
+        const int cnt = nsurv - base < G ? nsurv - base : G;
+        for (int j = 0; j < cnt; ++j) {
+            unsigned long long key = 0ull;
+            classify_chars(r.s1 + s_surv[base + j], r.s2, s_clsrank, s_codes + (size_t)j * region, 0, m, tid, T, key);
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(key, d, 64);
+                key = other > key ? other : key;
+            }
+            if (lane == 0) s_keys[j * WAVES + wave] = key;
+        }
+        __syncthreads();
+        if (wave < cnt) {
+            const int o = s_surv[base + wave];
+            WalkStats st = {0, 0, 0};
+            const double s = walk_sum(0.0, s_codes + (size_t)wave * region, 0, m, s_class, &s_walk[wave], r.fast_ok,
+                                      r.fast_min_exp, lane, st);
+            unsigned long long key = lane < WAVES ? s_keys[wave * WAVES + lane] : 0ull;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) {
+                const unsigned long long other = __shfl_xor(key, d, 64);
+                key = other > key ? other : key;
+            }
+            if (lane == 0) {
+                const int rank = (int)(key >> 32);
+                CandRec c;
+                c.offset = o;
+                c.rank = rank;
+                if (rank) {
+                    const int i = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
+                    c.score = s + r.delta_of_rank[rank];
+                    c.char_offset = i;
+                    c.ch = r.sub[(unsigned)r.s2[i] * kRow + r.s1[o + i]];
+                } else {
+                    c.score = r.delta_of_rank[0];
+                    c.char_offset = -1;
+                    c.ch = 0;
+                }
+                s_rec[base + wave] = c;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const bool is_max = r.is_max != 0;
+        int idx = -1;
+        for (int k = 0; k < nsurv; ++k)
+            if (s_rec[k].rank != 0 &&
+                (idx < 0 || rec_better(is_max, s_rec[k].score, s_rec[k].offset, s_rec[idx].score, s_rec[idx].offset)))
+                idx = k;
+        if (idx >= 0) {
+            const CandRec b = s_rec[idx];
+            write_search_tail(r, &b, 0);
+        } else {
+            write_search_tail(r, nullptr, 0);
+        }
+        // the search scalars are clean for the next search on this slot
+        store_agent(r.cand_count, 0);
+        store_agent(r.done, 0);
+        __hip_atomic_store(r.global_best, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // ---- count kernel --------------------------------------------------------------
 struct CountArgs {
     const unsigned char* s1;        // Seq1 symbol codes, padded with kCodePad (32 per slot)
@@ -558,6 +1048,11 @@ struct CountArgs {
         int*                cand_count;
         BoundParams         bounds;
     } sel[2];
+    // Single searches are ONE launch: the last tile workgroup to finish its selection ends the search (finish_search:
+    // final bound, surviving candidates, exact re-score, fold, tail).  `tail` = what psa_rescore_kernel would be given.
+    int         fused;
+    int         lds_bytes;            // dynamic LDS of the launch (the tail carves its buffers out of the dead planes)
+    RescoreArgs tail;
 };
 
 #ifdef PSA_PHASE_TIMING
@@ -730,12 +1225,28 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
             if (up[e] >= need) {
                 const int slot = atomicAdd(sel.cand_count, 1);
                 if (slot < a.cap) {
-                    sel.cand[slot] = a.first + (int)blockIdx.x * kTileStride + o_local + e - a.lead;
-                    sel.cand_upper[slot] = up[e];
+                    store_agent(sel.cand + slot, a.first + (int)blockIdx.x * kTileStride + o_local + e - a.lead);
+                    store_agent(sel.cand_upper + slot, up[e]);
                 }
             }
     }
     PSA_PHASE(6);
+    if (!a.fused) return;
+    // ---- a single search ends in this launch: the last tile workgroup to get here finishes it.  Producer side of
+    // the hand-off: the candidate stores above are write-through, every wave drains its own, the workgroup
+    // barrier, then ONE lane's arrival; the last arriver acquires.
+    __shared__ int s_last_tile;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const int arrived = __hip_atomic_fetch_add(a.tail.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last_tile = arrived == (int)gridDim.x - 1;
+        if (s_last_tile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    if (!s_last_tile) return;
+    finish_search<WAVES>(a.tail, reinterpret_cast<unsigned char*>(lds), a.lds_bytes, tid);
+    PSA_PHASE(7);
 }
 
 // ---- duo count kernel (batches) ------------------------------------------------
@@ -952,100 +1463,16 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
     }
 }
 
-// ---- rescore: the reference's sequential fp64 sum for each candidate -----------
-// One wave per candidate.  The additions of cpu_funcs.c:278 are a serial chain of
-// m roundings, but while the running sum stays inside one binade every addend is
-// rounded to that binade's ulp, i.e. the chain is an INTEGER walk in units of the
-// ulp:  S += R_e[class]  with R_e[c] = round(p_c / ulp_e).  Integer adds commute,
-// so a batch of 512 chars is summed with a wave-wide prefix scan and accepted when
-// every prefix stays strictly inside the binade (then each partial sum is provably
-// the reference's, see DESIGN.md "exact fast path"); the char that leaves the
-// binade, binades where an addend falls exactly between two grid points (a
-// round-half-even tie) and the first chars (|sum| comparable to the addends) run
-// the plain chain of v_add_f64.
-struct CandRec {                    // one re-scored candidate
-    double score;                   // exact total + best delta
-    int    offset;
-    int    char_offset;             // first char with the best delta rank
-    int    rank;                    // 0 = no substitution possible
-    int    ch;                      // substituted character
-};
-
-struct RescoreArgs {
-    const unsigned char* s1;
-    const unsigned char* s2;        // byte codes
-    const unsigned char* clsrank;   // [32][32]: class (bits 0-2) | delta rank (bits 3-7), [c2][c1]
-    const unsigned char* sub;       // [32][32]
-    const double*        delta_of_rank;
-    const int*           cand;
-    const double*        cand_upper;  // optimistic bounds of the candidates, or NULL (already filtered)
-    unsigned long long*  global_best; // final best pessimistic bound (ordered-u64)
-    int*                 cand_count;
-    CandRec*             rec;       // [cap]
-    int*                 done;      // arrival counter of the candidate workgroups
-    SearchTail*          out;       // written by the last workgroup to arrive
-    const int*           bad;       // the encode kernels' alphabet flag
-    long long            pairs;
-    int                  seq;       // sequence number of the search, echoed in the tail
-    double class_value[8];          // pair score of class 0..3, +0.0 for the padding class 4
-    int m;
-    int cap;
-    int is_max;
-    int fast_ok;                    // all weights normal doubles or zero
-    int fast_min_exp;               // smallest biased exponent of the running sum the walk handles
-    // blockIdx.y = query of a batch launch: its state lies query_stride... further on (all 0 for one search)
-    size_t s2_stride;               // bytes between the queries' codes
-    int    batched;                 // 1: cand/cand_upper/rec advance by cap, the scalars by kScalStride, out and seq by 1
-};
-
-#ifndef PSA_RESCORE_EPL
-#define PSA_RESCORE_EPL 8
-#endif
-constexpr int kRescoreEpl = PSA_RESCORE_EPL;   // chars per lane and batch on the integer walk
-constexpr int kRescoreThreads = 512;
-constexpr int kRescoreChunk = 32768;    // chars whose class codes are staged in LDS at a time
-constexpr int kRescoreGrid = 64;        // workgroups; each takes candidates ci = block, block + 64, ...
-constexpr int kRescorePadLds = 36 * 1024;   // + ~35 KB static: a rescore and a count workgroup never share a CU
-
-// Inclusive prefix sum of a 64-bit value over the 64 lanes, by DPP row shifts and row
-// broadcasts (register-to-register; no LDS round trips as __shfl_up would need).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ long long dpp_add(long long v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
-    return v + (long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo);
-}
-
-__device__ __forceinline__ long long wave_scan_inclusive(long long v)
-{
-    v = dpp_add<0x111, 0xf>(v);   // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);   // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);   // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);   // row_shr:8   -> inclusive scan inside each row of 16 lanes
-    v = dpp_add<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v = dpp_add<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-__device__ __forceinline__ long long readlane64(long long v, int l)
-{
-    const unsigned lo = __builtin_amdgcn_readlane((int)v, l);
-    const unsigned hi = __builtin_amdgcn_readlane((int)(v >> 32), l);
-    return (long long)(((unsigned long long)hi << 32) | lo);
-}
-
-// One workgroup per candidate.  All four waves classify the chars of a chunk into LDS
+// One workgroup per candidate.  All waves classify the chars of a chunk into LDS
 // (class | rank codes; loads of the whole chunk in flight together) and track the best
 // delta rank and its first position; wave 0 then runs the summation over the staged codes.
 __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArgs a)
 {
     __shared__ unsigned char      s_clsrank[kRow * kRow];
     __shared__ __attribute__((aligned(16))) unsigned char s_codes[kRescoreChunk + 64 * kRescoreEpl + 16];
-    __shared__ double             s_vals[64];
+    __shared__ WalkScratch        s_walk;
     __shared__ double             s_class[8];     // the class values, indexable (a by-value kernel argument indexed
                                                   // at run time would be copied to scratch by every lane)
-    __shared__ long long          s_round[8];
     __shared__ unsigned long long s_key[kRescoreThreads / 64];
     __shared__ int s_last;
     extern __shared__ unsigned char s_pad[];      // never touched: only makes the workgroup too big to share a
@@ -1077,12 +1504,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
         // stays, the host runs the selection once more against it (only a second overflow — more true
         // near-ties than the list holds — goes to the sequential engine).
         if (blockIdx.x == 0 && tid == 0) {
-            psa_result r;
-            r.score = 0.0; r.offset = -1; r.char_offset = -1; r.ch = 0; r.shard = -1; r.pairs = a.pairs;
-            a.out->result = r;
-            a.out->bad = *a.bad;
-            a.out->overflow = 1;
-            a.out->seq = a.seq;
+            write_search_tail(a, nullptr, 1);
             *a.cand_count = 0;
             *a.done = 0;
         }
@@ -1107,179 +1529,25 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
 
     double s = 0.0;                 // running sum (meaningful in wave 0), wave-uniform
     unsigned long long key = 0ull;  // per thread: max of (rank << 32 | ~i): best rank, then lowest i
+    WalkStats st = {0, 0, 0};
 
     for (int c0 = 0; c0 < m; c0 += kRescoreChunk) {
         const int c1 = c0 + kRescoreChunk < m ? c0 + kRescoreChunk : m;
-        // ---- classify the chunk (all waves): four chars per thread and step, several steps in flight
-        {
-            const int groups = (c1 - c0 + 64 * kRescoreEpl + 3) >> 2;
-#pragma unroll 4
-            for (int g = tid; g < groups; g += kRescoreThreads) {
-                const int i = c0 + 4 * g;                         // c0 and the Seq2 code buffer are 4-byte aligned
-                const unsigned w2 = *reinterpret_cast<const unsigned*>(a.s2 + i);   // both buffers are padded with
-                unsigned w1;                                                           // kCodePad (class 4, rank 0)
-                __builtin_memcpy(&w1, s1 + i, 4);
-                unsigned packed = 0u;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    unsigned cr = 4u;
-                    if (i + j < c1) {
-                        cr = s_clsrank[((w2 >> (8 * j)) & 0xffu) * kRow + ((w1 >> (8 * j)) & 0xffu)];
-                        const unsigned long long k2 = ((unsigned long long)(cr >> 3) << 32) | (0xffffffffu - (unsigned)(i + j));
-                        key = k2 > key ? k2 : key;
-                    }
-                    packed |= cr << (8 * j);
-                }
-                *reinterpret_cast<unsigned*>(s_codes + 4 * g) = packed;
-            }
-        }
+        classify_chars(s1, a.s2, s_clsrank, s_codes, c0, c1, tid, kRescoreThreads, key);
         __syncthreads();
         if (ci == (int)blockIdx.x) PSA_RPHASE(2);
         // ---- sum the chunk in reference order (wave 0)
-        if (tid < 64) {
-            int k = c0;
-#ifdef PSA_PHASE_TIMING
-            int dbg_chain = 0, dbg_batches = 0, dbg_left = 0;
-#endif
-            while (k < c1) {
-                const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
-                const int e = (int)((sb >> 52) & 0x7ff);
-                bool walk = a.fast_ok && e >= a.fast_min_exp && e < 0x7ff;
-                if (walk) {
-                    // R_e[c] for the five classes, and whether any addend ties in this binade
-                    long long r = 0;
-                    bool tie = false;
-                    if (lane < 5) {
-                        const unsigned long long pb = (unsigned long long)__double_as_longlong(s_class[lane]);
-                        const int ep = (int)((pb >> 52) & 0x7ff);
-                        if (ep != 0) {                           // zero stays 0 (subnormals excluded by fast_ok)
-                            const unsigned long long mp = (pb & 0xfffffffffffffull) | (1ull << 52);
-                            const int d = e - ep;                // >= 2 by fast_min_exp
-                            if (d <= 53) {
-                                const unsigned long long half = 1ull << (d - 1);
-                                tie = (mp & ((half << 1) - 1)) == half;
-                                const long long mag = (long long)((mp + half) >> d);
-                                r = (pb >> 63) ? -mag : mag;
-                            }
-                        }
-                        s_round[lane] = r;
-                    }
-                    if (__ballot(tie) != 0ull) walk = false;
-                }
-                if (!walk) {
-#ifdef PSA_PHASE_TIMING
-                    ++dbg_chain;
-#endif
-                    // plain chain over the next <= 64 chars; lanes past the chunk hold +0.0 (exact to add)
-                    const int nb = c1 - k < 64 ? c1 - k : 64;
-                    s_vals[lane] = lane < nb ? s_class[s_codes[k - c0 + lane] & 7u] : 0.0;
-                    __builtin_amdgcn_wave_barrier();
-                    const double2* v = reinterpret_cast<const double2*>(s_vals);   // same address in every lane: broadcast
-#pragma unroll
-                    for (int l = 0; l < 32; ++l) {
-                        const double2 x = v[l];
-                        s += x.x;                                 // reference order (cpu_funcs.c:278)
-                        s += x.y;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    k += nb;
-                    continue;
-                }
-                // integer walk inside binade e
-                __builtin_amdgcn_wave_barrier();
-                long long S = (long long)((sb & 0xfffffffffffffull) | (1ull << 52));
-                const bool neg = (sb >> 63) != 0;
-                if (neg) S = -S;
-                // |q| strictly inside (2^52, 2^53)  <=>  q strictly inside (bound_lo, bound_hi)
-                const long long bound_lo = neg ? -(1ll << 53) : (1ll << 52);
-                const long long bound_hi = neg ? -(1ll << 52) : (1ll << 53);
-                static_assert(kRescoreEpl % 8 == 0 && kRescoreEpl <= 16, "a lane's codes of one batch are 8-byte LDS words");
-                constexpr int kWords = kRescoreEpl / 8;
-                bool left = false;
-                while (k < c1 && !left) {
-                    // The batch starts at the kRescoreEpl-aligned position at or below k; chars below k are already
-                    // in S and count as padding (class 4, addend 0), like the staged positions past c1.
-                    const int k_al = k & ~(kRescoreEpl - 1);
-                    unsigned long long w[kWords];
-#pragma unroll
-                    for (int x = 0; x < kWords; ++x)
-                        w[x] = *reinterpret_cast<const unsigned long long*>(s_codes + (k_al - c0) + lane * kRescoreEpl + 8 * x);
-                    if (lane == 0 && k != k_al) {
-#pragma unroll
-                        for (int x = 0; x < kWords; ++x) {
-                            const int skip = k - k_al - 8 * x;                  // chars of this word already summed
-                            if (skip >= 8) w[x] = 0x0404040404040404ull;
-                            else if (skip > 0) {
-                                const unsigned long long keep = ~0ull << (8 * skip);
-                                w[x] = (w[x] & keep) | (0x0404040404040404ull & ~keep);
-                            }
-                        }
-                    }
-                    long long rr[kRescoreEpl];
-                    long long t = 0;
-#pragma unroll
-                    for (int j = 0; j < kRescoreEpl; ++j) {
-                        rr[j] = s_round[(unsigned)(w[j >> 3] >> (8 * (j & 7))) & 7u];
-                        t += rr[j];
-                    }
-#ifdef PSA_PHASE_TIMING
-                    ++dbg_batches;
-#endif
-                    const long long incl = wave_scan_inclusive(t);
-                    const long long q0 = S + (incl - t);          // sum before this lane's first char
-                    long long q = q0;
-                    bool inside = true;
-#pragma unroll
-                    for (int j = 0; j < kRescoreEpl; ++j) {
-                        q += rr[j];
-                        inside &= (q > bound_lo) & (q < bound_hi);
-                    }
-                    const unsigned long long bad_lanes = __ballot(!inside);
-                    if (bad_lanes == 0ull) {
-                        S = readlane64(q, 63);
-                        k = k_al + 64 * kRescoreEpl < c1 ? k_al + 64 * kRescoreEpl : c1;
-                    } else {
-                        // rare (once per binade change): find the first char that leaves the binade
-                        int bad = kRescoreEpl;
-                        long long prev = q0, run = q0;
-#pragma unroll
-                        for (int j = 0; j < kRescoreEpl; ++j) {
-                            const long long nxt = run + rr[j];
-                            if (!((nxt > bound_lo) & (nxt < bound_hi)) && bad == kRescoreEpl) { bad = j; prev = run; }
-                            run = nxt;
-                        }
-                        const int L = __ffsll((long long)bad_lanes) - 1;
-                        const int j = __builtin_amdgcn_readlane(bad, L);
-                        S = readlane64(prev, L);                  // the sum before the char that leaves the binade
-                        const int p = k_al + L * kRescoreEpl + j;
-                        k = p > k ? p : k;                        // (a skipped char can only "fail" with S on the binade's edge)
-                        left = true;
-                    }
-                }
-                const unsigned long long mag = (unsigned long long)(S < 0 ? -S : S);
-                s = __longlong_as_double((long long)((neg ? (1ull << 63) : 0ull) | ((unsigned long long)e << 52) |
-                                                     (mag & 0xfffffffffffffull)));
-#ifdef PSA_PHASE_TIMING
-                if (left) ++dbg_left;
-#endif
-                if (left) {
-                    // this char moves the sum out of the binade: one true fp64 add
-                    s += s_class[s_codes[k - c0] & 7u];
-                    k += 1;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-#ifdef PSA_PHASE_TIMING
-            if (tid == 0 && blockIdx.x == 0 && ci == 0) {      // how the walk of the first candidate went
-                g_phase_ts[1001][0] = (unsigned long long)dbg_chain;
-                g_phase_ts[1001][1] = (unsigned long long)dbg_batches;
-                g_phase_ts[1001][2] = (unsigned long long)dbg_left;
-            }
-#endif
-        }
+        if (tid < 64) s = walk_sum(s, s_codes, c0, c1, s_class, &s_walk, a.fast_ok, a.fast_min_exp, lane, st);
         if (ci == (int)blockIdx.x) PSA_RPHASE(3);
         __syncthreads();            // the next chunk overwrites s_codes
     }
+#ifdef PSA_PHASE_TIMING
+    if (tid == 0 && blockIdx.x == 0 && ci == 0) {      // how the walk of the first candidate went
+        g_phase_ts[1001][0] = (unsigned long long)st.chain;
+        g_phase_ts[1001][1] = (unsigned long long)st.batches;
+        g_phase_ts[1001][2] = (unsigned long long)st.left;
+    }
+#endif
 
     // best rank and its first position over all chars
 #pragma unroll
@@ -1343,25 +1611,12 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
             if (rec_better(is_max, s2, o2, bs, bo)) { bs = s2; bo = o2; idx = i2; }
         }
         if (lane == 0) {
-            psa_result r;
             if (idx >= 0) {
                 const CandRec b = a.rec[idx];
-                r.score = b.score;
-                r.offset = b.offset;
-                r.char_offset = b.char_offset;
-                r.ch = b.ch;
+                write_search_tail(a, &b, 0);
             } else {
-                r.score = is_max ? -INFINITY : INFINITY;
-                r.offset = -1;
-                r.char_offset = -1;
-                r.ch = 0;
+                write_search_tail(a, nullptr, 0);
             }
-            r.shard = -1;
-            r.pairs = a.pairs;
-            a.out->result = r;
-            a.out->bad = *a.bad;
-            a.out->overflow = 0;
-            a.out->seq = a.seq;
             // leave the search scalars clean for the next search on this slot
             *a.cand_count = 0;
             *a.done = 0;

@@ -224,7 +224,7 @@ extern "C" {
 
 const char* psa_last_error(void) { return psa::g_last_error.c_str(); }
 
-const char* psa_version(void) { return "psa_amd 0.2 (gfx950)"; }
+const char* psa_version(void) { return "psa_amd 0.3 (gfx950)"; }
 
 psa_status psa_build_tables(const double weights[4], int is_max,
                             double* P, unsigned char* SUB, double* DELTA, char* SIGN)
@@ -294,6 +294,48 @@ void psa_shard_range(int total_offsets, int nshards, int rank, int* first_offset
     if (rank == nshards - 1) hi += total_offsets % nshards;
     if (first_offset) *first_offset = lo;
     if (last_offset) *last_offset = hi;
+}
+
+// Queries of a batch over shards: blocks as even as possible (no reference rule: the reference has no batch)
+void psa_query_block(int nq, int nshards, int rank, int* first_query, int* last_query)
+{
+    if (nshards < 1) nshards = 1;
+    if (nq < 0) nq = 0;
+    const int base = nq / nshards, rem = nq % nshards;
+    const int lo = base * rank + (rank < rem ? rank : rem);
+    const int hi = lo + base + (rank < rem ? 1 : 0);
+    if (first_query) *first_query = lo;
+    if (last_query) *last_query = hi;
+}
+
+int psa_query_block_max(int nq, int nshards)
+{
+    if (nshards < 1) nshards = 1;
+    if (nq < 0) nq = 0;
+    return (nq + nshards - 1) / nshards;
+}
+
+psa_status psa_batch_unpack(const psa_result* gathered, int nq, int nshards, psa_result* results, psa_result* results_min)
+{
+    if (!gathered || !results || nq < 1 || nshards < 1) {
+        psa::set_last_error("psa_batch_unpack: bad arguments");
+        return PSA_ERR_ARG;
+    }
+    const int per = psa_query_block_max(nq, nshards);
+    for (int i = 0; i < nshards; ++i) {
+        int lo, hi;
+        psa_query_block(nq, nshards, i, &lo, &hi);
+        const psa_result* block = gathered + (size_t)i * 2 * per;
+        for (int q = lo; q < hi; ++q) {
+            results[q] = block[q - lo];
+            results[q].shard = q;
+            if (results_min) {
+                results_min[q] = block[per + (q - lo)];
+                results_min[q].shard = q;
+            }
+        }
+    }
+    return PSA_OK;
 }
 
 void psa_generate_sequence(uint64_t seed, int n, char* out)

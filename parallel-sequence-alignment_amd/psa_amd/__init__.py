@@ -22,6 +22,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PSA_AMD_LIB") or os.path.join(_HERE, "libpsa_amd.so")   # override: kernel experiments
 
 PSA_OK, PSA_ERR_ARG, PSA_ERR_ALPHABET, PSA_ERR_DEVICE, PSA_ERR_STATE = range(5)
+EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1
+# the reference's own (C++-mangled) name of gpu_run_program (cuda_funcs.h:33), exported next to the C name
+CXX_GPU_RUN_PROGRAM = "_Z15gpu_run_programP5_dataP7_mutantii"
 ENGINE_AUTO, ENGINE_SEQUENTIAL, ENGINE_FILTER = 0, 1, 2
 
 # every symbol include/psa.h declares (tests check the library exports all of them)
@@ -29,13 +32,14 @@ EXPORTED_SYMBOLS = (
     "gpu_run_program", "gpu_run_program_layout",
     "psa_create", "psa_destroy", "psa_set_weights",
     "psa_set_seq1", "psa_set_seq2", "psa_set_seq1_device", "psa_set_seq2_device",
+    "psa_set_sequences", "psa_set_sequences_device",
     "psa_set_engine", "psa_set_batch_streams", "psa_search", "psa_search_async", "psa_search_wait", "psa_scores",
     "psa_search_batch", "psa_search_batch_device",
     "psa_search_batch_minmax", "psa_search_batch_minmax_device",
-    "psa_debug_counts", "psa_fallback_count", "psa_reselect_count", "psa_duo_retry_count", "psa_debug_rescore",
-    "psa_group_create", "psa_group_destroy", "psa_group_size", "psa_group_set_weights",
+    "psa_debug_counts", "psa_fallback_count", "psa_reselect_count", "psa_unfused_count", "psa_duo_retry_count", "psa_debug_rescore",
+    "psa_group_create", "psa_group_create_ex", "psa_group_destroy", "psa_group_size", "psa_group_set_weights",
     "psa_group_set_seq1", "psa_group_set_seq2", "psa_search_sharded", "psa_search_batch_sharded",
-    "psa_fold", "psa_shard_range", "psa_build_tables",
+    "psa_fold", "psa_shard_range", "psa_query_block", "psa_query_block_max", "psa_batch_unpack", "psa_build_tables",
     "psa_set_profiling", "psa_last_timing", "psa_profile_totals", "psa_last_kernel_queries",
     "psa_generate_sequence", "psa_last_error", "psa_version",
 )
@@ -79,6 +83,8 @@ def _load() -> C.CDLL:
     lib.psa_set_seq2.argtypes = [vp, C.c_char_p, i]
     lib.psa_set_seq1_device.argtypes = [vp, vp, i]
     lib.psa_set_seq2_device.argtypes = [vp, vp, i]
+    lib.psa_set_sequences.argtypes = [vp, C.c_char_p, i, C.c_char_p, i]
+    lib.psa_set_sequences_device.argtypes = [vp, vp, i, vp, i]
     lib.psa_set_engine.argtypes = [vp, i]
     lib.psa_set_batch_streams.argtypes = [vp, i]
     lib.psa_search.argtypes = [vp, i, i, C.POINTER(Result)]
@@ -93,8 +99,10 @@ def _load() -> C.CDLL:
     lib.psa_fallback_count.argtypes = [vp]
     lib.psa_reselect_count.argtypes = [vp]
     lib.psa_duo_retry_count.argtypes = [vp]
+    lib.psa_unfused_count.argtypes = [vp]
     lib.psa_debug_rescore.argtypes = [vp, vp, i, vp]
     lib.psa_group_create.argtypes = [C.POINTER(i), i, C.POINTER(vp)]
+    lib.psa_group_create_ex.argtypes = [C.POINTER(i), i, i, C.POINTER(vp)]
     lib.psa_group_destroy.argtypes = [vp]
     lib.psa_group_destroy.restype = None
     lib.psa_group_size.argtypes = [vp]
@@ -106,6 +114,10 @@ def _load() -> C.CDLL:
     lib.psa_fold.argtypes = [C.POINTER(Result), i, i, C.POINTER(Result)]
     lib.psa_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.psa_shard_range.restype = None
+    lib.psa_query_block.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
+    lib.psa_query_block.restype = None
+    lib.psa_query_block_max.argtypes = [i, i]
+    lib.psa_batch_unpack.argtypes = [C.POINTER(Result), i, i, C.POINTER(Result), C.POINTER(Result)]
     lib.psa_build_tables.argtypes = [dp, i, vp, vp, vp, vp]
     lib.psa_set_profiling.argtypes = [vp, i]
     lib.psa_last_timing.argtypes = [vp, i, C.POINTER(C.c_float), C.POINTER(C.c_char_p)]
@@ -117,6 +129,9 @@ def _load() -> C.CDLL:
     lib.gpu_run_program.restype = d
     lib.gpu_run_program_layout.argtypes = [vp, C.c_size_t, C.c_size_t, C.POINTER(Mutant), i, i]
     lib.gpu_run_program_layout.restype = d
+    cxx = getattr(lib, CXX_GPU_RUN_PROGRAM)
+    cxx.argtypes = [vp, C.POINTER(Mutant), i, i]
+    cxx.restype = d
     return lib
 
 
@@ -179,6 +194,25 @@ def shard_range(total_offsets: int, nshards: int, rank: int):
     return lo.value, hi.value
 
 
+def query_block(nq: int, nshards: int, rank: int):
+    """Queries [lo, hi) of shard `rank` when nq queries are dealt to nshards shards (psa_query_block)."""
+    lo, hi = C.c_int(), C.c_int()
+    lib.psa_query_block(nq, nshards, rank, C.byref(lo), C.byref(hi))
+    return lo.value, hi.value
+
+
+def query_block_max(nq: int, nshards: int) -> int:
+    return lib.psa_query_block_max(nq, nshards)
+
+
+def batch_unpack(gathered: Sequence[Result], nq: int, nshards: int, minmax: bool = False):
+    """The batch exchange's gathered blocks -> results in query order (psa_batch_unpack)."""
+    arr = (Result * len(gathered))(*gathered)
+    hi, lo = (Result * nq)(), (Result * nq)()
+    _check(lib.psa_batch_unpack(arr, nq, nshards, hi, lo if minmax else None))
+    return (list(hi), list(lo)) if minmax else list(hi)
+
+
 def fold(records: Sequence[Result], is_max: bool) -> Result:
     arr = (Result * len(records))(*records)
     out = Result()
@@ -217,6 +251,15 @@ class Context:
     def set_seq2(self, seq2: bytes):
         _check(lib.psa_set_seq2(self._h, seq2, len(seq2)))
         self.m = len(seq2)
+
+    def set_sequences(self, seq1: bytes, seq2: bytes):
+        """Both sequences at once: one encode launch (psa_set_sequences)."""
+        _check(lib.psa_set_sequences(self._h, seq1, len(seq1), seq2, len(seq2)))
+        self.n, self.m = len(seq1), len(seq2)
+
+    def set_sequences_device(self, ptr1: int, n: int, ptr2: int, m: int):
+        _check(lib.psa_set_sequences_device(self._h, C.c_void_p(ptr1), n, C.c_void_p(ptr2), m))
+        self.n, self.m = n, m
 
     def set_seq1_device(self, ptr: int, n: int):
         _check(lib.psa_set_seq1_device(self._h, C.c_void_p(ptr), n))
@@ -329,6 +372,10 @@ class Context:
         """Batches redone without the batch count kernel after one of its group barriers timed out."""
         return lib.psa_duo_retry_count(self._h)
 
+    def unfused_count(self) -> int:
+        """Single filter searches finished by a second launch (psa_rescore_kernel) instead of inside the count kernel."""
+        return lib.psa_unfused_count(self._h)
+
     def reselect_count(self) -> int:
         """Searches whose candidate selection ran twice (overflow against the running bound)."""
         return lib.psa_reselect_count(self._h)
@@ -357,10 +404,11 @@ class Group:
     """Device group (psa_group_create .. psa_group_destroy): one search sharded over several GPUs of the node,
     per-device records exchanged by one RCCL all-gather (the reference's MPI layer, cpu_funcs.c:49-94)."""
 
-    def __init__(self, devices: Sequence[int]):
+    def __init__(self, devices: Sequence[int], exchange: int = EXCHANGE_RCCL):
+        """exchange = EXCHANGE_HOST: the records meet in host memory (no RCCL; a device may be listed several times)."""
         self._h = C.c_void_p()
         arr = (C.c_int * len(devices))(*devices)
-        _check(lib.psa_group_create(arr, len(devices), C.byref(self._h)))
+        _check(lib.psa_group_create_ex(arr, len(devices), exchange, C.byref(self._h)))
         self.n = self.m = None
 
     def close(self):

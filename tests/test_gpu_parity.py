@@ -482,6 +482,113 @@ def test_sharded_search_through_the_c_abi(psa, oracle, reference_records):
         psa.Group([0, 0])                                     # a device listed twice
 
 
+@pytest.mark.parametrize("ndev", [2, 3, 8])
+def test_group_of_several_contexts_host_exchange(psa, oracle, reference_records, ndev):
+    """The N-way split behind the C ABI with N > 1 on the one-GPU box: N contexts on device 0 whose records meet in host
+    memory (PSA_EXCHANGE_HOST; RCCL wants one rank per GPU).  Everything but the all-gather itself is the multi-GPU
+    path: psa_shard_range split (cpu_funcs.c:128-133), each shard's last kernel writing its record into the
+    exchange's send buffer, empty shards, the is_swapable fold (cpu_funcs.c:71-94), and the batch deal."""
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch, r.shard, r.pairs)
+    with psa.Group([0] * ndev, psa.EXCHANGE_HOST) as g, psa.Context(0) as c:
+        assert g.size() == ndev
+        for rec in (5, 0, 9, 11):         # rounding trap; output.txt; 89 exact ties (second launch); 2 offsets (empty shards)
+            w, s1, s2, is_max = reference_records[rec]
+            g.set_weights(w, is_max)
+            g.set_seq1(s1)
+            g.set_seq2(s2)
+            res, shards = g.search()
+            assert_same(res, oracle.search(s1, s2, w, is_max, threads=4))
+            total = len(s1) - len(s2) + 1
+            assert res.pairs == total * len(s2) and [r.shard for r in shards] == list(range(ndev))
+            c.set_weights(w, is_max)
+            c.set_seq1(s1)
+            c.set_seq2(s2)
+            for r in range(ndev):
+                lo, hi = psa.shard_range(total, ndev, r)
+                if hi > lo:
+                    want = c.search(lo, hi)
+                    assert key(shards[r])[:4] == key(want)[:4] and shards[r].pairs == want.pairs
+                else:
+                    assert shards[r].offset == -1 and shards[r].pairs == 0
+            # a sub-range, twice (the second search finds the first one's records in the send buffers)
+            if total > 40:
+                for _ in range(2):
+                    res, _ = g.search(17, total - 5)
+                    assert_same(res, oracle.search(s1, s2, w, is_max, 17, total - 5, threads=4))
+        # batches whose size the devices do not divide (ADVICE r2: the last block used to overrun the exchange block)
+        w, s1, s2, is_max = reference_records[0]
+        g.set_weights(w, is_max)
+        g.set_seq1(s1)
+        c.set_weights(w, is_max)
+        c.set_seq1(s1)
+        for nq in (3, 7, 13):
+            qs = [psa.generate_sequence(5100 + q, 650) for q in range(nq)]
+            qs[nq - 1] = s1[2000:2650]
+            got = g.search_batch(qs)
+            hi, lo = g.search_batch(qs, minmax=True)
+            want = c.search_batch(qs)
+            want_hi, want_lo = c.search_batch_minmax(qs)
+            assert [key(r) for r in got] == [key(r) for r in want]
+            assert [key(r) for r in hi] == [key(r) for r in want_hi] and [key(r) for r in lo] == [key(r) for r in want_lo]
+
+
+def test_single_search_is_one_launch_unless_too_many_survive(psa, oracle, reference_records):
+    """A single filter search ends inside the count kernel: its last tile workgroup re-scores the survivors (<= 16, one
+    wave each) and writes the tail.  Record 9 has 89 exact ties -> they all survive the final bound -> the tail asks
+    for psa_rescore_kernel (psa_unfused_count); record 13 has 18; records 0 / 5 and the synthetic pair stay fused."""
+    with psa.Context(0) as c:
+        c.set_engine(psa.ENGINE_FILTER)
+        for rec, second_launch in ((0, False), (5, None), (9, True), (13, True), (1, None)):
+            w, s1, s2, is_max = reference_records[rec]
+            before = c.unfused_count()
+            res = run(c, s1, s2, w, is_max)
+            assert_same(res, oracle.search(s1, s2, w, is_max, threads=4))
+            if second_launch is not None:
+                assert (c.unfused_count() > before) == second_launch, rec
+        s1, s2 = psa.generate_sequence(91, 300_000), psa.generate_sequence(92, 3000)
+        before = c.unfused_count()
+        for is_max in (True, False):
+            c.set_weights(W_README, is_max)
+            c.set_sequences(s1, s2)                     # both sequences, one encode launch
+            res = c.search()
+            assert_same(res, oracle.search(s1, s2, W_README, is_max, threads=8))
+        assert c.unfused_count() == before and c.fallback_count() == 0 and c.reselect_count() == 0
+
+
+def test_set_sequences_equals_the_two_setters(psa):
+    """psa_set_sequences / psa_set_sequences_device (one encode launch for both sequences) == psa_set_seq1 + psa_set_seq2,
+    for adjacent host buffers (one copy command), separate ones, device buffers, and a bad character in either."""
+    import torch
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch, r.pairs)
+    s1, s2 = psa.generate_sequence(61, 50_001), psa.generate_sequence(62, 777)
+    with psa.Context(0) as c:
+        c.set_weights(W_README, True)
+        c.set_seq1(s1)
+        c.set_seq2(s2)
+        want = key(c.search())
+        c.set_sequences(s1, s2)
+        assert key(c.search()) == want
+        blob = s1 + b"\0" + s2                           # the two arrays of a ProgramData: side by side
+        buf = C.create_string_buffer(blob, len(blob))
+        base = C.addressof(buf)
+        assert psa.lib.psa_set_sequences(c._h, C.cast(base, C.c_char_p), len(s1), C.cast(base + len(s1) + 1, C.c_char_p), len(s2)) == 0
+        c.n, c.m = len(s1), len(s2)
+        assert key(c.search()) == want
+        t1 = torch.frombuffer(bytearray(s1), dtype=torch.uint8).cuda()
+        t2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        c.set_sequences_device(t1.data_ptr(), len(s1), t2.data_ptr(), len(s2))
+        assert key(c.search()) == want
+        for bad1, bad2 in ((True, False), (False, True)):
+            b1 = s1[:100] + (b"a" if bad1 else b"A") + s1[101:]
+            b2 = s2[:5] + (b"?" if bad2 else b"A") + s2[6:]
+            with pytest.raises(psa.PsaError) as e:
+                c.set_sequences(b1, b2)
+            assert e.value.status == psa.PSA_ERR_ALPHABET
+        c.set_sequences(s1, s2)
+        assert key(c.search()) == want
+
+
 def test_drop_in_program_with_psa_devices(psa, tmp_path):
     """PSA_DEVICES routes the drop-in binary through the device group (here: a group of one)."""
     import shutil
@@ -493,6 +600,12 @@ def test_drop_in_program_with_psa_devices(psa, tmp_path):
     p = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=120, env=env)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "processes= 1" in p.stdout
+    assert (tmp_path / "output.txt").read_bytes() == open(os.path.join(GOLDEN, "reference_output.txt"), "rb").read()
+    # a 4-way split rehearsed on the one GPU: four contexts on device 0, records exchanged through host memory
+    os.remove(tmp_path / "output.txt")
+    env = dict(os.environ, PSA_DEVICES="0,0,0,0", PSA_EXCHANGE="host")
+    p = subprocess.run([exe], cwd=tmp_path, capture_output=True, text=True, timeout=120, env=env)
+    assert p.returncode == 0, p.stdout + p.stderr
     assert (tmp_path / "output.txt").read_bytes() == open(os.path.join(GOLDEN, "reference_output.txt"), "rb").read()
 
 
@@ -585,6 +698,13 @@ def test_stock_reference_caller_links_and_runs(psa, oracle, reference_records, t
     total = len(s1) - len(s2) + 1
     score, off, ci, ch = oracle.search(s1, s2, w, is_max, total // 2, total, threads=4)
     assert lines[1] == "%d %d %s %g" % (off, ci, ch, score)
+    # the same caller built as the reference builds its files: C++, no extern "C" -> the mangled name (cuda_funcs.h:33)
+    exe = tmp_path / "stock_caller_cxx"
+    subprocess.run(["g++", "-O2", "-Wall", "-o", str(exe), os.path.join(ROOT, "tests", "c", "stock_caller.cpp"),
+                    "-L", lib_dir, "-lpsa_amd", f"-Wl,-rpath,{lib_dir}"], check=True, capture_output=True, text=True)
+    run = subprocess.run([str(exe), os.path.join(GOLDEN, "reference_input.txt")], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    assert run.stdout.splitlines() == lines
 
 
 def test_filter_engine_synthetic_golden_and_ranges(psa, oracle):

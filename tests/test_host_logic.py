@@ -60,6 +60,89 @@ def test_shard_range_is_reference_rule(psa):
             assert ranges[0][0] == 0 and ranges[-1][1] == total
 
 
+@pytest.mark.parametrize("nq,nshards", [(3, 8), (7, 4), (100, 8), (256, 8), (1, 1), (5, 5), (9, 2), (257, 3)])
+def test_query_blocks_cover_the_batch_and_fit_the_exchange_block(psa, nq, nshards):
+    """psa_query_block: contiguous blocks, as even as possible, every block <= psa_query_block_max (the size of a
+    device's block in the batch exchange — a block that is larger would overrun it)."""
+    blocks = [psa.query_block(nq, nshards, r) for r in range(nshards)]
+    per = psa.query_block_max(nq, nshards)
+    assert per == -(-nq // nshards)
+    assert blocks[0][0] == 0 and blocks[-1][1] == nq
+    for (lo, hi), (lo2, _) in zip(blocks, blocks[1:]):
+        assert hi == lo2
+    sizes = [hi - lo for lo, hi in blocks]
+    assert all(0 <= s <= per for s in sizes) and max(sizes) - min(sizes) <= 1
+    assert sizes == sorted(sizes, reverse=True)
+
+
+@pytest.mark.parametrize("minmax", [False, True])
+@pytest.mark.parametrize("nq,nshards", [(3, 8), (7, 4), (100, 8), (256, 8), (2, 3)])
+def test_batch_exchange_layout_round_trip(psa, nq, nshards, minmax):
+    """The batch exchange without devices: every shard packs its block [mode][per] as psa_search_batch_sharded does, a
+    fake gather puts the blocks side by side, psa_batch_unpack returns every query's record(s) in query order."""
+    per = psa.query_block_max(nq, nshards)
+
+    def rec(q, mode):
+        r = psa.Result()
+        r.score, r.offset, r.char_offset, r.ch, r.shard, r.pairs = q + 0.25 * mode, 10 * q + mode, q % 7, 65 + q % 26, -7, 1000 + q
+        return r
+
+    pad = psa.Result()
+    pad.offset, pad.shard = -1, -1
+    gathered = []
+    for shard in range(nshards):
+        lo, hi = psa.query_block(nq, nshards, shard)
+        block = [pad] * (2 * per)
+        for q in range(lo, hi):
+            block[q - lo] = rec(q, 0)
+            if minmax:
+                block[per + q - lo] = rec(q, 1)
+        gathered += block
+    out = psa.batch_unpack(gathered, nq, nshards, minmax)
+    hi_, lo_ = out if minmax else (out, None)
+    assert [(r.score, r.offset, r.shard, r.pairs) for r in hi_] == [(float(q), 10 * q, q, 1000 + q) for q in range(nq)]
+    if minmax:
+        assert [(r.score, r.offset, r.shard) for r in lo_] == [(q + 0.25, 10 * q + 1, q) for q in range(nq)]
+
+
+def test_only_the_c_abi_is_exported(psa):
+    """Built with -fvisibility=hidden and a version script: the dynamic symbols are the C ABI of psa.h plus the
+    reference's C++-mangled name of gpu_run_program (cuda_funcs.h:33; the reference has no extern "C")."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", psa.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    names = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert names == set(psa.EXPORTED_SYMBOLS) | {psa.CXX_GPU_RUN_PROGRAM}
+
+
+def test_plain_symbol_detects_a_caller_with_other_array_limits(psa, tmp_path):
+    """gpu_run_program by name reads the stock 10001 / 5001 layout.  A caller that binds it with this repo's
+    1,000,001 / 10,001 struct (no psa.h) is told so: no NUL inside seq1[10001] -> message + exit(EXIT_FAILURE), like
+    every error of the reference's entry point (cuda_funcs.cu:44-48); a short Seq1 leaves an empty seq2 at the stock
+    offset -> message, 'nothing found'.  Both before any device is touched."""
+    import subprocess
+    import sys
+    from conftest import PKG
+    script = tmp_path / "wrong_layout.py"
+    script.write_text(
+        "import ctypes as C, sys\n"
+        f"sys.path.insert(0, {PKG!r})\n"
+        "import psa_amd as psa\n"
+        "n = int(sys.argv[1]); cap1, cap2 = 1000001, 10001\n"
+        "blob = bytearray(40 + cap1 + cap2)\n"
+        "blob[0:4] = (1).to_bytes(4, 'little')\n"
+        "blob[40:40 + n] = b'A' * n\n"
+        "blob[40 + cap1:40 + cap1 + 5] = b'ACDEF'\n"
+        "data = (C.c_char * len(blob)).from_buffer(blob)\n"
+        "m = psa.Mutant()\n"
+        "s = psa.lib.gpu_run_program(C.addressof(data), C.byref(m), 0, 10)\n"
+        "print('returned', s, m.offset)\n")
+    run = subprocess.run([sys.executable, str(script), "20000"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 1 and "other array limits" in run.stderr and "returned" not in run.stdout
+    run = subprocess.run([sys.executable, str(script), "300"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "seq2 is empty" in run.stderr
+    assert run.stdout.split()[:3] == ["returned", "-inf", "-1"]
+
+
 def test_fold_order_matches_is_swapable(psa, oracle):
     """psa_fold == repeated is_swapable (cuda_funcs.cu:290-307), any arrival order."""
     rng = np.random.default_rng(7)
@@ -177,11 +260,17 @@ def test_drop_in_program_sign_table(psa):
 
 
 def test_stock_reference_caller_links(psa, tmp_path):
-    """The reference-style caller (its own structs and prototype, no header of this repo) compiles and links against
-    libpsa_amd.so by symbol name — the link-time half of the drop-in claim (the run is a GPU test)."""
+    """The reference-style callers (their own structs and prototype, no header of this repo) compile and link against
+    libpsa_amd.so by symbol name — the link-time half of the drop-in claim (the runs are GPU tests): as C, and as
+    C++ without extern "C" the way the reference is built (Makefile:9-12), which refers to the mangled name."""
     import subprocess
     from conftest import PKG, ROOT
     lib_dir = os.path.join(PKG, "psa_amd")
     subprocess.run(["gcc", "-O2", "-std=c11", "-Wall", "-Werror", "-o", str(tmp_path / "stock_caller"),
                     os.path.join(ROOT, "tests", "c", "stock_caller.c"), "-L", lib_dir, "-lpsa_amd",
                     f"-Wl,-rpath,{lib_dir}"], check=True, capture_output=True, text=True)
+    exe = tmp_path / "stock_caller_cxx"
+    subprocess.run(["g++", "-O2", "-Wall", "-Werror", "-o", str(exe), os.path.join(ROOT, "tests", "c", "stock_caller.cpp"),
+                    "-L", lib_dir, "-lpsa_amd", f"-Wl,-rpath,{lib_dir}"], check=True, capture_output=True, text=True)
+    undefined = subprocess.run(["nm", "-u", str(exe)], check=True, capture_output=True, text=True).stdout
+    assert psa.CXX_GPU_RUN_PROGRAM in undefined
