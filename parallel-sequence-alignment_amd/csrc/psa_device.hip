@@ -15,6 +15,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +40,16 @@ struct SearchTail {   // everything the host reads back after a search, one D2H 
     int        seq;       // echo of the search's sequence number: proves this tail belongs to it
     int        pad;
 };
+
+// The tail lives in pinned host memory the host may be POLLING (psa_search_wait does not wait for the kernel's end
+// signal): everything else first, then the search's number as a system-scope release store.
+__device__ __forceinline__ void publish_tail(SearchTail* out, const psa_result& r, int bad, int overflow, int seq)
+{
+    out->result = r;
+    out->bad = bad;
+    out->overflow = overflow;
+    __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 struct BlockRec {     // per-block / per-shard arg-best
     double score;
@@ -201,14 +213,12 @@ __device__ __forceinline__ void finalize_write(const FinalArgs& a, psa_result r)
 {
     r.shard = -1;
     r.pairs = a.pairs;
-    a.out->result = r;
-    a.out->bad = *a.bad;
-    a.out->overflow = 0;
-    a.out->seq = a.seq;
     if (a.record_out) {
-        r.shard = a.record_shard;
-        *a.record_out = r;
+        psa_result x = r;
+        x.shard = a.record_shard;
+        *a.record_out = x;
     }
+    publish_tail(a.out, r, *a.bad, 0, a.seq);
 }
 
 __global__ __launch_bounds__(kBlock) void psa_finalize_kernel(FinalArgs a)
@@ -791,7 +801,6 @@ static_assert((kMaxChunks + 1) * psa::kClasses * psa::kUnroll + psa::kUnroll <= 
 bool plan_filter(int first, int last, int m, FilterPlan* best, int max_chunks)
 {
     const int ntiles = (last - (first & ~31) + psa::kTileStride - 1) / psa::kTileStride;
-    const int cells = psa::kCellDwords * 4;              // the epilogue's count cells reuse the plane rows
     const int rounds_total = ((m + psa::kClasses - 1) / psa::kClasses + psa::kUnroll - 1) / psa::kUnroll;   // per class
     double best_cost = 0.0;
     bool found = false;
@@ -812,8 +821,7 @@ bool plan_filter(int first, int last, int m, FilterPlan* best, int max_chunks)
             if (wave_classes * class_chars > psa::kMaxWaveChars) continue;
             const int slots = psa::kTile / 32 + class_chars + 1;
             if (slots > psa::kRowSlots) continue;             // rows are kRowSlots slots apart in LDS
-            int lds = psa::kMaskRows * psa::kRowSlots * 8;    // one workgroup per CU
-            if (cells > lds) lds = cells;
+            const int lds = psa::kCountLdsBytes;              // plane rows + count cells: one workgroup per CU
             if (lds > kLdsLimit) continue;
             const long long blocks = (long long)ntiles * nchunks;
             const long long rounds_cu = (blocks + 255) / 256;        // waves of co-resident workgroups
@@ -917,12 +925,23 @@ psa::RescoreArgs rescore_args(const psa_context* c, const SearchSlot& s, long lo
             if (e > max_exp) max_exp = e;
         }
 #ifdef PSA_EXPERIMENT
-        static const bool chain_only = std::getenv("PSA_RESCORE_CHAIN") != nullptr;   // experiment knob
+        const bool chain_only = std::getenv("PSA_RESCORE_CHAIN") != nullptr;   // experiment knob
 #else
         constexpr bool chain_only = false;
 #endif
         r.fast_ok = ok && !chain_only;
         r.fast_min_exp = max_exp + 2;
+#ifdef PSA_EXPERIMENT
+        const bool walk_only = std::getenv("PSA_RESCORE_WALK") != nullptr;     // experiment knob: no certified sums
+#else
+        constexpr bool walk_only = false;
+#endif
+        // |sequential fp64 prefix sum - exact prefix sum| <= (k-1) u sum|p_i| / (1 - k u) <= m u m wmax; doubled, and the
+        // order-free evaluation certified_sum compares with adds a few roundings of its own (far inside the factor)
+        double wmax = 0.0;
+        for (int i = 0; i < 4; ++i) wmax = std::fmax(wmax, std::fabs(r.class_value[i]));
+        r.walk_slack = 2.1 * ((double)s.m + 32.0) * 1.1102230246251565e-16 * ((double)s.m * wmax);
+        r.certify = r.fast_ok && !walk_only && s.m < 65536 && std::isfinite(r.walk_slack);
     }
     r.batched = 0;
     r.s2_stride = 0;
@@ -1527,6 +1546,26 @@ static psa_status settle_search(psa_context* c)
     return PSA_OK;
 }
 
+// The search's last kernel writes its 48-byte tail straight into pinned host memory, its sequence number last (a
+// system-scope release).  Watching that word returns the result a few microseconds before the stream's completion
+// signal would (hipStreamSynchronize: kernel end, signal, runtime wake-up); a search that takes longer than a
+// short spin falls back to it.  Everything the host touches afterwards is ordered behind the kernel by the stream.
+static bool tail_arrived(const psa_context* c, double spin_us)
+{
+    const volatile int* seq = &c->h_tails[0].seq;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int k = 0; k < 256; ++k) {
+            if (*seq == c->seq) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return true;
+            }
+            __builtin_ia32_pause();
+        }
+        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > spin_us) return false;
+    }
+}
+
 psa_status psa_search_wait(psa_context* c, psa_result* out)
 {
     if (!c || !out) { set_last_error("psa_search_wait: NULL argument"); return PSA_ERR_ARG; }
@@ -1534,7 +1573,7 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));                // (a group waits for several devices' searches in turn; the retry
                                               // paths launch kernels)
-    PSA_HIP(hipStreamSynchronize(c->stream));
+    if (c->profiling || !tail_arrived(c, 400.0)) PSA_HIP(hipStreamSynchronize(c->stream));
     c->pending = false;
     const psa_status st = settle_search(c);
     c->record_out = nullptr;
@@ -1911,7 +1950,7 @@ psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_sta
 
 #ifdef PSA_PHASE_TIMING
 // debug build only (tools/phase_timing.py): the count kernel's phase timestamps
-int psa_debug_phase_ts(unsigned long long* out /* [1024][8] */)
+PSA_EXPORT int psa_debug_phase_ts(unsigned long long* out /* [1024][8] */)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psa::g_phase_ts), sizeof(unsigned long long) * 1024 * 8);
 }

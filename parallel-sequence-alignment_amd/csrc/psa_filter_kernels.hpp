@@ -426,6 +426,8 @@ __device__ __forceinline__ void count_classes(Counter (&cnt)[2][kCounters],
 // so the two halves never carry into each other.
 constexpr int kTileWords = kTile / 32;
 constexpr int kCellDwords = kCounters * 16 * kTileWords;
+constexpr int kPlaneBytes = kMaskRows * kRowSlots * 8;          // the class-plane rows of a tile in LDS
+constexpr int kCountLdsBytes = kPlaneBytes + kCellDwords * 4;   // dynamic LDS of psa_count_kernel: planes + count cells
 
 // 16 plane words (planes 0..15 of 32 positions) -> 16 dwords, dword t = count(t) | count(t+16) << 16:
 // the lower four stages of the 32x32 bit-matrix transpose (Hacker's Delight 7-3), applied to both
@@ -613,6 +615,8 @@ struct RescoreArgs {
     int is_max;
     int fast_ok;                    // all weights normal doubles or zero
     int fast_min_exp;               // smallest biased exponent of the running sum the walk handles
+    int certify;                    // 1: try the certified segment sum first (certified_sum), the walk is its fallback
+    double walk_slack;              // rigorous bound of |sequential fp64 prefix sum - order-free prefix sum| over the m chars
     // blockIdx.y = query of a batch launch: its state lies query_stride... further on (all 0 for one search)
     size_t s2_stride;               // bytes between the queries' codes
     int    batched;                 // 1: cand/cand_upper/rec advance by cap, the scalars by kScalStride, out and seq by 1
@@ -828,7 +832,194 @@ __device__ __forceinline__ double walk_sum(double s, const unsigned char* s_code
     return s;
 }
 
-// is_swapable (cuda_funcs.cu:290-307) over re-scored candidates; rank 0 = "no substitution possible": never wins
+// ---- the same sum without walking: certified segments ---------------------------------
+// walk_sum is a chain of ~25 dependent wave steps (14 us for 10,000 chars).  Most of it can be known without walking.
+// Let P_k be the exact (real-number) prefix sum after char k and s_k the reference's sequentially rounded one:
+// |s_k - P_k| <= slack for every k (the standard bound (k-1) u sum|p_i|; the host passes it doubled).  A char k is
+// INTERIOR when an order-free evaluation of P_{k-1} and P_k puts both at least `slack` inside the same binade
+// (2^e, 2^(e+1)) of the same sign, e large enough for the integer walk: then s_{k-1} and s_k certainly lie in that
+// binade, and the reference's addition fl(s_{k-1} + p_k) is the integer step S += R_e[class] (both multiples of
+// ulp_e, no tie — walk_sum's argument).  Every other char (a binade change, a prefix sum within slack of a power of
+// two, the first chars near zero) is a TRUE fp64 addition.  The classification is parallel work for the whole
+// workgroup (prefix class counts by a scan, one fp64 add and a few compares per char); what remains serial is one wave
+// walking the few true additions, with an interior run between two of them being cnt[class] x R_e[class] from the prefix
+// counts.  Nothing is assumed: a tie in a run's binade, a run that would leave its binade or too many true additions
+// send the candidate to walk_sum.
+constexpr int kCertMaxTrue = 384;         // true additions one wave takes before the walk is the better tool
+
+struct CertLayout {                       // per candidate, in LDS behind its class codes
+    int chars_per_thread;                 // L: thread t classifies chars [t L, (t+1) L)
+    int nwords;                           // words of the true-addition bit mask
+};
+
+__host__ __device__ inline int cert_chars_per_thread(int m, int nthreads)
+{
+    return (((m + nthreads - 1) / nthreads) + 3) & ~3;
+}
+// bytes behind a candidate's codes: packed prefix counts per thread + the bit mask
+__host__ __device__ inline int cert_bytes(int m, int nthreads)
+{
+    return nthreads * 8 + (((m + 31) / 32 * 4 + 15) & ~15);
+}
+
+// Parallel part (every thread of the workgroup; contains workgroup barriers).  wbase[t] = class counts of the chars
+// in front of thread t's first char, 16 bits per class; bit k of nonint = char k takes a true addition;
+// *s_true = how many.  s_wsum: NT / 64 words of scratch.
+template <int NT>
+__device__ __forceinline__ void certify_chars(const unsigned char* s_codes, int m, const double* s_class, double slack,
+                                              int fast_min_exp, unsigned long long* wbase, unsigned* nonint,
+                                              unsigned long long* s_wsum, int* s_true, int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int L = cert_chars_per_thread(m, NT);
+    const int nwords = (m + 31) / 32;
+    for (int i = tid; i < nwords; i += NT) nonint[i] = 0u;
+    if (tid == 0) *s_true = 0;
+    const int k0 = tid * L;
+    const int k1 = k0 + L < m ? k0 + L : m;
+    unsigned long long local = 0ull;
+    for (int k = k0; k < k1; k += 4) {                 // (the codes behind m are class 4: counted nowhere)
+        const unsigned w = *reinterpret_cast<const unsigned*>(s_codes + k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned cls = (w >> (8 * j)) & 7u;
+            if (cls < 4u) local += 1ull << (16 * cls);
+        }
+    }
+    const unsigned long long incl = (unsigned long long)wave_scan_inclusive((long long)local);
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    unsigned long long base = incl - local;
+    for (int w = 0; w < wave; ++w) base += s_wsum[w];
+    wbase[tid] = base;
+    if (k0 < m) {
+        // order-free prefix sum in front of this thread's chars, then one addition per char (its own rounding is far
+        // inside the doubled slack)
+        double p = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p += s_class[c] * (double)(unsigned)((base >> (16 * c)) & 0xffffull);
+        auto classify = [&](double x, unsigned& key, bool& safe) {
+            const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+            key = (unsigned)(b >> 52);
+            const unsigned e = key & 0x7ffu;
+            const double a = __longlong_as_double((long long)(b & 0x7fffffffffffffffull));
+            const double lo = __longlong_as_double((long long)((unsigned long long)e << 52));
+            const double hi = __longlong_as_double((long long)((unsigned long long)(e + 1u) << 52));
+            safe = (int)e >= fast_min_exp && e < 0x7feu && a - lo >= slack && hi - a >= slack;
+        };
+        unsigned key_prev;
+        bool safe_prev;
+        classify(p, key_prev, safe_prev);
+        unsigned bits = 0u;
+        int ntrue = 0;
+        for (int k = k0; k < k1; ++k) {
+            p += s_class[s_codes[k] & 7u];
+            unsigned key;
+            bool safe;
+            classify(p, key, safe);
+            const bool interior = safe && safe_prev && key == key_prev;
+            if (!interior) { bits |= 1u << (k & 31); ++ntrue; }
+            key_prev = key;
+            safe_prev = safe;
+            if ((k & 31) == 31 || k == k1 - 1) {
+                if (bits) atomicOr(&nonint[k >> 5], bits);
+                bits = 0u;
+            }
+        }
+        if (ntrue) atomicAdd(s_true, ntrue);
+    }
+    __syncthreads();
+}
+
+// Serial part: ONE wave (all 64 lanes, same arguments).  Returns false when the candidate has to be walked instead.
+template <int NT>
+__device__ __forceinline__ bool certified_sum(const unsigned char* s_codes, int m, const double* s_class,
+                                              const unsigned long long* wbase, const unsigned* nonint, int ntrue,
+                                              WalkScratch* ws, int lane, double& s_out)
+{
+    if (ntrue > kCertMaxTrue) return false;
+    const int L = cert_chars_per_thread(m, NT);
+    if (L > 64) return false;
+    const int nwords = (m + 31) / 32;
+    // class counts of the chars in front of char x (wave-uniform)
+    auto prefix = [&](int x) -> unsigned long long {
+        const int t = x > 0 ? (x - 1) / L : 0, r = x - t * L;          // (0 <= r <= L <= 64)
+        const unsigned cls = lane < r ? (unsigned)(s_codes[t * L + lane] & 7u) : 7u;
+        unsigned long long c = wbase[t];
+#pragma unroll
+        for (unsigned k = 0; k < 4u; ++k) c += (unsigned long long)__popcll(__ballot(cls == k)) << (16 * k);
+        return c;
+    };
+    double s = 0.0;
+    int k = 0;
+    bool failed = false;
+    // chars [k, upto) are interior: integer steps in the binade of s
+    auto run = [&](int upto) {
+        if (upto <= k || failed) return;
+        const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
+        const int e = (int)((sb >> 52) & 0x7ff);
+        long long r = 0;
+        bool tie = false;
+        if (lane < 4) {
+            const unsigned long long pb = (unsigned long long)__double_as_longlong(s_class[lane]);
+            const int ep = (int)((pb >> 52) & 0x7ff);
+            if (ep != 0) {
+                const unsigned long long mp = (pb & 0xfffffffffffffull) | (1ull << 52);
+                const int d = e - ep;
+                if (d < 2) tie = true;                   // (cannot happen for a certified binade: fast_min_exp)
+                else if (d <= 53) {
+                    const unsigned long long half = 1ull << (d - 1);
+                    tie = (mp & ((half << 1) - 1)) == half;
+                    const long long mag = (long long)((mp + half) >> d);
+                    r = (pb >> 63) ? -mag : mag;
+                }
+            }
+            ws->round[lane] = r;
+        }
+        if (__ballot(tie) != 0ull) { failed = true; return; }
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long cnt = prefix(upto) - prefix(k);      // per class, no borrows: the counts only grow
+        long long S = (long long)((sb & 0xfffffffffffffull) | (1ull << 52));
+        const bool neg = (sb >> 63) != 0;
+        if (neg) S = -S;
+        unsigned long long delta = 0ull;                              // (wraps; the certified total fits)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) delta += ((cnt >> (16 * c)) & 0xffffull) * (unsigned long long)ws->round[c];
+        S += (long long)delta;
+        const long long bound_lo = neg ? -(1ll << 53) : (1ll << 52);
+        const long long bound_hi = neg ? -(1ll << 52) : (1ll << 53);
+        if (!((S > bound_lo) & (S < bound_hi))) { failed = true; return; }   // the certificate says this cannot happen
+        const unsigned long long mag = (unsigned long long)(S < 0 ? -S : S);
+        s = __longlong_as_double((long long)((neg ? (1ull << 63) : 0ull) | ((unsigned long long)e << 52) |
+                                             (mag & 0xfffffffffffffull)));
+        __builtin_amdgcn_wave_barrier();
+        k = upto;
+    };
+    for (int w0 = 0; w0 < nwords && !failed; w0 += 64) {
+        const unsigned mine = w0 + lane < nwords ? nonint[w0 + lane] : 0u;
+        unsigned long long lanes = __ballot(mine != 0u);
+        while (lanes && !failed) {
+            const int l = __ffsll((long long)lanes) - 1;
+            lanes &= lanes - 1;
+            unsigned word = (unsigned)__builtin_amdgcn_readlane((int)mine, l);
+            while (word && !failed) {
+                const int b = __ffs((int)word) - 1;
+                word &= word - 1;
+                const int at = (w0 + l) * 32 + b;
+                run(at);
+                if (failed) break;
+                s += s_class[s_codes[at] & 7u];           // the reference's own addition (cpu_funcs.c:278)
+                k = at + 1;
+            }
+        }
+    }
+    run(m);
+    if (failed) return false;
+    s_out = s;
+    return true;
+}
+
+// what the host reads after a search (pinned, host-coherent memory written over PCIe by one lane)
 __device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const CandRec* best, int status)
 {
     const bool is_max = a.is_max != 0;
@@ -846,16 +1037,14 @@ __device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const Ca
     }
     r.shard = -1;
     r.pairs = a.pairs;
-    a.out->result = r;
-    a.out->bad = *a.bad;
-    a.out->overflow = status;
-    a.out->seq = a.seq;
     if (a.record_out) {
         // the record a device group exchanges: shard = the shard's index, or -2 - status when the host has to look
         // at this search again (candidate list overflow, separate re-score launch)
-        r.shard = status ? -2 - status : a.record_shard;
-        *a.record_out = r;
+        psa_result x = r;
+        x.shard = status ? -2 - status : a.record_shard;
+        *a.record_out = x;
     }
+    publish_tail(a.out, r, *a.bad, status, a.seq);
 }
 
 // ---- values other workgroups wrote / will read inside the same launch ----------------
@@ -894,10 +1083,13 @@ constexpr int kFusedMax = 16;
 constexpr int kFusedWaves = 16;
 // LDS in front of the candidates' class codes (finish_search's carve-up) and how many candidates' codes fit at a time
 constexpr int kFusedFixedBytes = kRow * kRow + 8 * (int)sizeof(double) + kFusedWaves * (int)sizeof(WalkScratch) +
-                                 kFusedMax * kFusedWaves * 8 + kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4 + 16;
+                                 kFusedMax * kFusedWaves * 8 + kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4 + 16 +
+                                 kFusedWaves * 8 + kFusedMax * 4;
+// LDS of one candidate: its class codes + the walk's over-read, the certificate's prefix counts and bit mask
+__host__ __device__ inline int fused_codes_bytes(int m) { return (m + 64 * kRescoreEpl + 16 + 15) & ~15; }
 __host__ __device__ inline int fused_candidates_at_a_time(int lds_bytes, int m)
 {
-    const int region = (m + 64 * kRescoreEpl + 16 + 15) & ~15;       // one candidate's codes + the walk's over-read
+    const int region = fused_codes_bytes(m) + cert_bytes(m, kFusedWaves * 64);
     const int g = (lds_bytes - kFusedFixedBytes) / region;
     return g > kFusedWaves ? kFusedWaves : g;
 }
@@ -918,9 +1110,12 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     CandRec* s_rec = reinterpret_cast<CandRec*>(p);                           p += kFusedMax * sizeof(CandRec);
     int* s_surv = reinterpret_cast<int*>(p);                                  p += kFusedMax * 4;
     int* s_n = reinterpret_cast<int*>(p);                                     p += 16;
+    unsigned long long* s_wsum = reinterpret_cast<unsigned long long*>(p);    p += WAVES * 8;
+    int* s_true = reinterpret_cast<int*>(p);                                  p += kFusedMax * 4;
     unsigned char* s_codes = p;
     const int m = r.m;
-    const int region = (m + 64 * kRescoreEpl + 16 + 15) & ~15;               // codes of one candidate + the walk's over-read
+    const int codes_bytes = fused_codes_bytes(m);
+    const int region = codes_bytes + cert_bytes(m, T);                       // per candidate: codes, prefix counts, bit mask
     static_assert(WAVES == kFusedWaves, "kFusedFixedBytes is this carve-up for 16 waves");
     const int G = fused_candidates_at_a_time(lds_bytes, m);                  // candidates classified at a time
 
@@ -969,11 +1164,23 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
             if (lane == 0) s_keys[j * WAVES + wave] = key;
         }
         __syncthreads();
+        if (r.certify)
+            for (int j = 0; j < cnt; ++j) {
+                unsigned char* mine = s_codes + (size_t)j * region;
+                certify_chars<T>(mine, m, s_class, r.walk_slack, r.fast_min_exp,
+                                 reinterpret_cast<unsigned long long*>(mine + codes_bytes),
+                                 reinterpret_cast<unsigned*>(mine + codes_bytes + T * 8), s_wsum, &s_true[j], tid);
+            }
         if (wave < cnt) {
             const int o = s_surv[base + wave];
+            const unsigned char* mine = s_codes + (size_t)wave * region;
             WalkStats st = {0, 0, 0};
-            const double s = walk_sum(0.0, s_codes + (size_t)wave * region, 0, m, s_class, &s_walk[wave], r.fast_ok,
-                                      r.fast_min_exp, lane, st);
+            double s = 0.0;
+            if (!r.certify ||
+                !certified_sum<T>(mine, m, s_class, reinterpret_cast<const unsigned long long*>(mine + codes_bytes),
+                                  reinterpret_cast<const unsigned*>(mine + codes_bytes + T * 8), s_true[wave],
+                                  &s_walk[wave], lane, s))
+                s = walk_sum(0.0, mine, 0, m, s_class, &s_walk[wave], r.fast_ok, r.fast_min_exp, lane, st);
             unsigned long long key = lane < WAVES ? s_keys[wave * WAVES + lane] : 0ull;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
@@ -1085,7 +1292,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     // (symbol_planes: bit b = the relation of that Seq1 symbol to b) and transposes the two 32x32
     // bit matrices in registers — 14 KB of codes read per workgroup instead of 100 KB of planes.
     __shared__ unsigned s_planes[64];
+    // The tile's count cells have LDS of their own behind the plane rows and start from zero, so a wave adds its counts
+    // the moment its main loop ends — the older waves of a SIMD finish 20 us before the youngest, and their
+    // transposes and ds_adds run under the others' main loops.
+    unsigned* const cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + kPlaneBytes);
     PSA_PHASE(0);
+    for (int i = tid; i < kCellDwords; i += WAVES * 64) cells[i] = 0u;
     {
         // the lower half of the workgroup transposes the lo planes, the upper half the hi planes;
         // a thread's first 32 codes are fetched together with the symbol table (one memory latency)
@@ -1139,12 +1351,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     // registers, two 16-bit counts per dword) and adds them to the tile's cells in LDS (ds_add_u32);
     // each thread then picks up the counts of its offsets.
     PSA_PHASE(2);
-    __syncthreads();                                 // rows no longer needed: LDS is scratch now
-    PSA_PHASE(3);
-    unsigned* cells = reinterpret_cast<unsigned*>(lds);
-    for (int i = tid; i < kCellDwords; i += WAVES * 64) cells[i] = 0u;
-    __syncthreads();
+    // the running best bound of every mode, asked for now and used after the barrier (the selection below only needs
+    // A lower bound of the final best: a value a few microseconds old is as good)
+    unsigned long long running[2];
+#pragma unroll
+    for (int mode = 0; mode < 2; ++mode)
+        running[mode] = a.inline_select && mode < a.nmodes ? load_agent(a.sel[mode].global_best) : 0ull;
     add_counts_to_cells(cnt, cells, kTileWords, lane, true);
+    PSA_PHASE(3);
     PSA_PHASE(4);
     __syncthreads();
 
@@ -1195,38 +1409,42 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     }
     // the counts are final
     PSA_PHASE(5);
-    unsigned long long* s_best = reinterpret_cast<unsigned long long*>(cells);    // (every thread has read its cells)
+    __shared__ unsigned long long s_best[2][WAVES];
+    double up[2][kPer];
     for (int mode = 0; mode < a.nmodes; ++mode) {
-        const CountArgs::CountSelect& sel = a.sel[mode];
-        __syncthreads();                              // everyone is done reading the cells / the previous mode's s_best
-        double up[kPer];
         // offsets relative to the range's first one; the tile answers for its first kTileStride positions
-        const double pess = thread_bounds<kPer>(sel.bounds, n, (int)blockIdx.x * kTileStride + o_local - a.lead, a.span,
-                                                kTileStride - o_local, up);
+        const double pess = thread_bounds<kPer>(a.sel[mode].bounds, n, (int)blockIdx.x * kTileStride + o_local - a.lead,
+                                                a.span, kTileStride - o_local, up[mode]);
         unsigned long long key = order_key(pess);
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             const unsigned long long other = __shfl_xor(key, d, 64);
             key = other > key ? other : key;
         }
-        if (lane == 0) s_best[wave] = key;
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < WAVES; ++w) key = s_best[w] > key ? s_best[w] : key;
-            // running best over the tiles finished so far: a lower bound of the final best, so selecting
-            // against it keeps a superset of the true candidates (the re-score kernel re-checks)
-            const unsigned long long old = atomicMax(sel.global_best, key);
-            s_best[WAVES] = old > key ? old : key;
+        if (lane == 0) s_best[mode][wave] = key;
+    }
+    __syncthreads();
+    for (int mode = 0; mode < a.nmodes; ++mode) {
+        const CountArgs::CountSelect& sel = a.sel[mode];
+        unsigned long long key = s_best[mode][lane & (WAVES - 1)];            // the tile's best pessimistic bound
+#pragma unroll
+        for (int d = WAVES / 2; d >= 1; d >>= 1) {
+            const unsigned long long other = __shfl_xor(key, d, 64);
+            key = other > key ? other : key;
         }
-        __syncthreads();
-        const double need = key_order(s_best[WAVES]);
+        // Candidates = offsets whose optimistic bound reaches the best pessimistic bound known: the tile's own and the
+        // running best over the tiles that finished earlier — a lower bound of the final best, so this keeps a
+        // superset of the true candidates (whoever re-scores re-checks against the final bound).
+        if (tid == 0) atomicMax(sel.global_best, key);                        // (no return value: nobody waits for it)
+        const unsigned long long need_key = mode == 0 ? running[0] : running[1];
+        const double need = key_order(need_key > key ? need_key : key);
 #pragma unroll
         for (int e = 0; e < kPer; ++e)
-            if (up[e] >= need) {
+            if (up[mode][e] >= need) {
                 const int slot = atomicAdd(sel.cand_count, 1);
                 if (slot < a.cap) {
                     store_agent(sel.cand + slot, a.first + (int)blockIdx.x * kTileStride + o_local + e - a.lead);
-                    store_agent(sel.cand_upper + slot, up[e]);
+                    store_agent(sel.cand_upper + slot, up[mode][e]);
                 }
             }
     }
@@ -1474,6 +1692,10 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     __shared__ double             s_class[8];     // the class values, indexable (a by-value kernel argument indexed
                                                   // at run time would be copied to scratch by every lane)
     __shared__ unsigned long long s_key[kRescoreThreads / 64];
+    __shared__ unsigned long long s_wbase[kRescoreThreads];                     // certified_sum: prefix class counts ...
+    __shared__ unsigned           s_nonint[(kRescoreChunk + 31) / 32];          // ... and the true-addition bit mask
+    __shared__ unsigned long long s_wsum[kRescoreThreads / 64];
+    __shared__ int s_true;
     __shared__ int s_last;
     extern __shared__ unsigned char s_pad[];      // never touched: only makes the workgroup too big to share a
     (void)s_pad;                                  // CU with a count-kernel workgroup (LDS), see launch site
@@ -1536,8 +1758,16 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
         classify_chars(s1, a.s2, s_clsrank, s_codes, c0, c1, tid, kRescoreThreads, key);
         __syncthreads();
         if (ci == (int)blockIdx.x) PSA_RPHASE(2);
-        // ---- sum the chunk in reference order (wave 0)
-        if (tid < 64) s = walk_sum(s, s_codes, c0, c1, s_class, &s_walk, a.fast_ok, a.fast_min_exp, lane, st);
+        // ---- sum the chunk in reference order (wave 0): certified segments when the whole Seq2 is staged, else the walk
+        const bool certify = a.certify && m <= kRescoreChunk;
+        if (certify) certify_chars<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, s_wbase, s_nonint,
+                                                    s_wsum, &s_true, tid);
+        if (tid < 64) {
+            if (!certify || !certified_sum<kRescoreThreads>(s_codes, m, s_class, s_wbase, s_nonint, s_true, &s_walk, lane, s)) {
+                st.left += 1000;                        // (phase-timing builds: the walk was needed)
+                s = walk_sum(s, s_codes, c0, c1, s_class, &s_walk, a.fast_ok, a.fast_min_exp, lane, st);
+            }
+        }
         if (ci == (int)blockIdx.x) PSA_RPHASE(3);
         __syncthreads();            // the next chunk overwrites s_codes
     }

@@ -776,6 +776,27 @@ def test_rescore_walk_is_bit_exact(psa, oracle, w):
                 assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (w, is_max, len(s2))
 
 
+@pytest.mark.parametrize("knob", ["PSA_RESCORE_WALK", "PSA_RESCORE_CHAIN"])
+def test_rescore_fallbacks_are_bit_exact(psa_debug, oracle, monkeypatch, knob):
+    """The exact re-score has three tiers: certified segment sums (default), the integer walk (its fallback), the plain
+    fp64 chain (the walk's fallback).  The debug library can switch the upper tiers off: the lower ones alone still
+    give the oracle's sum for every offset, and so does a whole search."""
+    psa = psa_debug
+    monkeypatch.setenv(knob, "1")
+    s1, s2 = psa.generate_sequence(71, 6000), psa.generate_sequence(72, 4000)
+    with psa.Context(0) as c:
+        for w in (W_README, [0.8, 0.54, 2.6, 13.7]):
+            for is_max in (True, False):
+                c.set_weights(w, is_max)
+                c.set_sequences(s1, s2)
+                offs = np.arange(len(s1) - len(s2) + 1, dtype=np.int32)
+                got = c.debug_rescore(offs)
+                want, _, _ = oracle.scores(s1, s2, w, is_max)
+                assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (knob, w, is_max)
+                c.set_engine(psa.ENGINE_FILTER)
+                assert_same(c.search(), oracle.search(s1, s2, w, is_max, threads=4))
+
+
 def test_batch_matches_oracle_and_single_searches(psa, oracle):
     """psa_search_batch: per-query results == oracle (small) and == psa_search (1M x 10k), both engines,
     including a query whose candidate list overflows (falls back inside the batch)."""

@@ -37,6 +37,10 @@ for k, name in enumerate(names):
     d = (ts[:, k + 1] - ts[:, k]) / 100.0
     print(f"{name:22s} mean {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
 print("result", r)
+tail = ts[ts[:, 7] > 0]
+for row in tail:     # the workgroup that finished the search (finish_search)
+    print(f"fused tail (last tile workgroup): select end -> tail written {(row[7] - row[6]) / 100.0:.2f} us; "
+          f"kernel start -> end {(row[7] - t0) / 100.0:.2f} us")
 
 # re-score kernel (workgroup 0, its first candidate)
 ctx.debug_rescore(np.array([r.offset, 5, 77777], dtype=np.int32))
