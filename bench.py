@@ -8,12 +8,14 @@ library's seeded generator, weights 1.5 2.6 0.3 0.2).
 A step is one pass of the hot path over one batch: Q independent Seq2 queries
 (default 256 as in BASELINE.json configs[4], seeds 2002+q) against the same Seq1
 (seed 1002) — every offset of every query scored, every best mutant known on the
-host.  The step starts from the raw ASCII sequences resident in HBM, so symbol
-encoding is inside the timed region (`batch_from_host` reports the same step
-handed over as pageable HOST buffers, PCIe included; it is never `value`).
+host.  `value` starts from the raw ASCII sequences resident in HBM (symbol
+encoding is inside the timed region), as the bench contract asks.  The SAME step
+handed over as pageable HOST buffers — the reference's own timed region,
+cpu_funcs.c:57-62: inputs in host memory -> best mutants on the host, PCIe
+included — is reported next to it as `timed_region_8d`.
 Query 0 is BASELINE.json configs[2]; the run checks its MAX and MIN answers
-against the committed oracle goldens and exits non-zero on any mismatch
-(`verified`).
+against the committed oracle goldens and exits non-zero on any mismatch, on a
+retried batch or on a sequential-engine fallback (`verified`).
 
   python bench.py [--gpus N] [--steps K] [--warmup W]
 
@@ -28,12 +30,14 @@ continue per rank; per-GPU work fixed), no data-path collective; ONE RCCL
 all-reduce(sum) per step of a one-hot [N*Q,4] int64 buffer leaves all 32-byte
 records on every rank (the argmax exchange of north_star).  `--scaling strong`
 deals the Q queries of configs[4] to the ranks instead.  `--mode shard` runs
-configs[3]: one query, offsets split like the reference's MPI ranks
-(cpu_funcs.c:128-133), one all-reduce of the per-rank records, fold with the
+configs[3]: the offsets split like the reference's MPI ranks (cpu_funcs.c:128-133),
+every rank searches its shard — one query, or `--queries Q` queries in flight per
+rank (throughput mode) — one all-reduce of the per-rank records, fold with the
 is_swapable order (cpu_funcs.c:71-94 replaced by one collective).
 """
 import argparse
 import glob
+import hashlib
 import json
 import os
 import socket
@@ -63,11 +67,14 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=1_000_000)
     ap.add_argument("--m", type=int, default=10_000)
-    ap.add_argument("--queries", type=int, default=256, help="Seq2 queries per step (batch mode)")
+    ap.add_argument("--queries", type=int, default=None,
+                    help="Seq2 queries per step: 256 in batch mode; in shard mode queries in flight per rank (default 1)")
     ap.add_argument("--mode", choices=("batch", "shard"), default="batch")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="N > 1, batch mode: weak = Q queries per rank, strong = Q queries dealt to the ranks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed region, the kernel probe and the self-check (profiling passes)")
     ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--batch-streams", type=int, default=1, choices=(1, 2),
                     help="2: a batch's count launches alternate between two streams (psa_set_batch_streams)")
@@ -79,7 +86,10 @@ def parse_args(argv=None):
                     help="rehearsal on a one-GPU box: every rank uses device 0 (needs --backend gloo; not a scaling measurement)")
     ap.add_argument("--stub-search", action="store_true",
                     help="launcher / exchange rehearsal without a GPU: gloo, records made up from the query index")
-    return ap.parse_args(argv)
+    args = ap.parse_args(argv)
+    if args.queries is None:
+        args.queries = 256 if args.mode == "batch" else 1
+    return args
 
 
 # --------------------------------------------------------------------------------------
@@ -127,12 +137,24 @@ def exchange_and_fold(psa, dist, torch, rec, rank, world, is_max, device):
     return psa.fold(recs, is_max)
 
 
+def exchange_and_fold_many(psa, dist, torch, recs, rank, world, is_max, device):
+    """Throughput-mode shard: every rank holds one record per query; one all-reduce of [world * Q] records, then the
+    is_swapable fold per query."""
+    nq = len(recs)
+    allr = gather_records(psa, dist, torch, recs, rank * nq, world * nq, device)
+    out = []
+    for q in range(nq):
+        per_rank = [allr[r * nq + q] for r in range(world)]
+        for r, x in enumerate(per_rank):
+            x.shard = r
+        out.append(psa.fold(per_rank, is_max))
+    return out
+
+
 def query_block(nq, world, rank):
-    """Contiguous block of queries of `rank` (the last rank takes the remainder, as cpu_funcs.c:128-133)."""
-    per = nq // world
-    lo = per * rank
-    hi = lo + per + (nq % world if rank == world - 1 else 0)
-    return lo, hi
+    """Contiguous block of queries of `rank`: as even as possible (psa_query_block, the library's own deal)."""
+    import psa_amd as psa
+    return psa.query_block(nq, world, rank)
 
 
 def host_cores():
@@ -172,6 +194,17 @@ def cpu_baseline(s1, s2, total, m, budget_s=9.0, threads=None):
     dt = time.perf_counter() - t0
     return {"value": sample * m / dt, "unit": "char-pair scores/s", "cores": cores, "kind": "port",
             "sample": f"offsets [0,{sample}) of query 0 (1M x 10k MAX), {cores} OpenMP threads, {dt:.2f} s"}
+
+
+def csrc_sha256():
+    """Hash of the kernel sources the library is built from: the committed PMC counters are only evidence for the
+    binary that was profiled (profiles/rNN_meta.json records this hash at profiling time)."""
+    h = hashlib.sha256()
+    for path in sorted(glob.glob(os.path.join(PKG, "csrc", "*"))):
+        if path.endswith((".hip", ".hpp", ".cpp")):
+            h.update(os.path.basename(path).encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()
 
 
 def latest_profile(pattern):
@@ -225,6 +258,18 @@ def stub_main(args, world, rank):
     return 0 if ok else 1
 
 
+def median_us(fn, sync, reps=24, warm=4):
+    """Median wall time of fn() in microseconds, device idle before every call."""
+    t = []
+    for k in range(reps + warm):
+        sync()
+        t0 = time.perf_counter()
+        fn()
+        if k >= warm:
+            t.append(time.perf_counter() - t0)
+    return 1e6 * sorted(t)[len(t) // 2]
+
+
 def main():
     args = parse_args()
     if args.gpus < 1:
@@ -268,19 +313,25 @@ def main():
     weak = args.mode == "batch" and args.scaling == "weak" and not emulated
     eff_world = args.emulate_world if emulated else world
     eff_rank = 0 if emulated else rank
-    # queries this rank holds: weak = its own Q (seeds continue across ranks), strong = all Q (it searches a block)
-    nq = args.queries if args.mode == "batch" else 1
+    extras = rank == 0 and world == 1 and not emulated and not args.no_extras
+    # queries this rank holds: weak = its own Q (seeds continue across ranks), strong / shard = all Q
+    nq = args.queries
     seed0 = SEED_QUERY0 + (rank * nq if weak else 0)
     s1 = psa.generate_sequence_np(SEED_SEQ1, n)
     queries = np.stack([psa.generate_sequence_np(seed0 + q, m) for q in range(nq)])
     t1 = torch.from_numpy(s1).to(device)          # inputs resident in HBM before the timed region
     tq = torch.from_numpy(queries).to(device)
+    h1 = s1.tobytes()
+    hq_all = [queries[q].tobytes() for q in range(nq)]
 
     stream = torch.cuda.current_stream(device)
     ctx = psa.Context(local_rank, stream.cuda_stream)
     ctx.set_engine(args.engine)
     ctx.set_batch_streams(args.batch_streams)
     ctx.set_weights(WEIGHTS, True)
+
+    def sync():
+        torch.cuda.synchronize(device)
 
     if args.mode == "batch":
         qlo, qhi = (0, nq) if weak else query_block(nq, eff_world, eff_rank)
@@ -296,25 +347,29 @@ def main():
                 return gather_records(psa, dist, torch, mine, slot0, total_q, xdev)
             return mine
     else:
+        qlo, qhi, slot0, total_q = 0, nq, 0, nq
         first, last = psa.shard_range(total, eff_world, eff_rank)
-        pairs_step = (last - first if emulated else total) * m
+        pairs_step = nq * (last - first if emulated else total) * m
 
         def step():
-            ctx.set_seq1_device(t1.data_ptr(), n)
-            ctx.set_seq2_device(tq[0].data_ptr(), m)
-            rec = ctx.search(first, last)
+            if nq == 1:
+                ctx.set_sequences_device(t1.data_ptr(), n, tq[0].data_ptr(), m)
+                recs = [ctx.search(first, last)]
+            else:                                                 # throughput mode: nq queries in flight on this shard
+                ctx.set_seq1_device(t1.data_ptr(), n)
+                recs = ctx.search_batch_device(tq.data_ptr(), nq, m, m, first, last)
             if world > 1:
-                rec = exchange_and_fold(psa, dist, torch, rec, rank, world, True, xdev)
-            return [rec]
+                recs = exchange_and_fold_many(psa, dist, torch, recs, rank, world, True, xdev)
+            return recs
 
     def timed(fn, steps):
         if dist:
             dist.barrier()
-        torch.cuda.synchronize(device)
+        sync()
         t0 = time.perf_counter()
         for _ in range(steps):
             out = fn()
-        torch.cuda.synchronize(device)
+        sync()
         if dist:
             dist.barrier()
         elapsed = time.perf_counter() - t0
@@ -333,7 +388,8 @@ def main():
     # (psa_search_batch_minmax).  Reported beside the headline, which stays the MAX-only batch.
     minmax = None
     mm = None
-    from_host = None
+    region_8d = None
+    from_host_equal = True
     if args.mode == "batch":
         def step_minmax():
             ctx.set_seq1_device(t1.data_ptr(), n)
@@ -350,47 +406,61 @@ def main():
                           "bounds / candidates / exact re-score are per mode; 'equivalent' counts the pairs two "
                           "separate searches would score"}
 
-        # SURVEY.md 8(d) region: the same step with the sequences handed over as pageable HOST buffers
-        # (psa_set_seq1 + psa_search_batch: H2D over PCIe inside the timed region).  Never `value`.
-        h1 = s1.tobytes()
-        hq = [queries[q].tobytes() for q in range(qlo, qhi)]
+        # SURVEY.md 8(d) / cpu_funcs.c:57-62: the same step with the sequences handed over as pageable HOST buffers
+        # (psa_set_seq1 + psa_search_batch: H2D over PCIe inside the timed region).
+        hq = hq_all[qlo:qhi]
 
         def step_from_host():
             ctx.set_seq1(h1)
             return ctx.search_batch(hq) if hq else []
         step_from_host()
-        fh_elapsed, fh = timed(step_from_host, max(2, args.steps // 2))
-        from_host = {"ms_per_step": 1e3 * fh_elapsed / max(2, args.steps // 2),
-                     "value": pairs_step * max(2, args.steps // 2) / fh_elapsed, "unit": "char-pair scores/s",
-                     "note": "psa_set_seq1 + psa_search_batch from pageable host memory (1 MB + Q x 10 kB over PCIe "
-                             "per step); `value` above starts from HBM-resident inputs"}
+        fh_steps = max(2, args.steps // 2)
+        fh_elapsed, fh = timed(step_from_host, fh_steps)
+        region_8d = {"ms_per_step": 1e3 * fh_elapsed / fh_steps, "value": pairs_step * fh_steps / fh_elapsed,
+                     "unit": "char-pair scores/s",
+                     "note": "the reference's timed region (cpu_funcs.c:57-62; SURVEY.md 8(d)): inputs in pageable host memory -> "
+                             "every best mutant on the host: psa_set_seq1 + psa_search_batch, 1 MB + Q x 10 kB over PCIe per "
+                             "step.  `value` is the same step from HBM-resident inputs, which is what the bench contract asks "
+                             "for as the headline"}
         from_host_equal = [r.as_tuple() for r in fh] == [r.as_tuple() for r in (results[slot0:slot0 + qhi - qlo] if world > 1 else results)]
 
-    # End-to-end latency of ONE blocking search of query 0, again from raw ASCII in HBM
-    # (library profiling off: its event records would sit between the kernels).
+    cpu = cpu4 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # (between the GPU legs: a utilisation sampler that looks every few seconds sees GPU work before and after)
+        cpu = cpu_baseline(h1, hq_all[0], total, m)
+        cpu4 = cpu_baseline(h1, hq_all[0], total, m, budget_s=4.0, threads=4)     # the reference's THREADS_COUNT, def.h:18
+
+    # ---- end-to-end latency of ONE blocking search of query 0 ------------------------------------------------
+    # (library profiling off: its event records would sit between the kernels)
     ctx.set_profiling(False)
-    lat = []
     lo1, hi1 = (first, last) if args.mode == "shard" else (0, total)
-    for k in range(12):
-        torch.cuda.synchronize(device)
-        t0 = time.perf_counter()
-        ctx.set_seq1_device(t1.data_ptr(), n)
-        ctx.set_seq2_device(tq[0].data_ptr(), m)
-        one = ctx.search(lo1, hi1)
-        if k >= 2:
-            lat.append(time.perf_counter() - t0)
-    # the same search handed over as HOST buffers (what gpu_run_program receives): H2D over PCIe included
-    host_lat = []
-    h1, h2 = s1.tobytes(), queries[0].tobytes()
-    for k in range(7):
-        t0 = time.perf_counter()
-        ctx.set_seq1(h1)
-        ctx.set_seq2(h2)
-        ctx.search(lo1, hi1)
-        if k >= 2:
-            host_lat.append(time.perf_counter() - t0)
+    h2 = hq_all[0]
+    p1, p2 = t1.data_ptr(), tq[0].data_ptr()
+
+    def one_search():                       # raw ASCII in HBM -> best mutant on the host: one encode launch + one search launch
+        ctx.set_sequences_device(p1, n, p2, m)
+        return ctx.search(lo1, hi1)
+
+    def one_search_two_setters():           # the same through the two separate setters (two encode launches)
+        ctx.set_seq1_device(p1, n)
+        ctx.set_seq2_device(p2, m)
+        return ctx.search(lo1, hi1)
+
+    def one_search_from_host():             # host buffers: H2D over PCIe included
+        ctx.set_sequences(h1, h2)
+        return ctx.search(lo1, hi1)
+
+    single = {"latency_us": median_us(one_search, sync),
+              "two_setters_us": median_us(one_search_two_setters, sync, reps=12),
+              "search_only_us": median_us(lambda: ctx.search(lo1, hi1), sync),
+              "from_host_buffers_us": median_us(one_search_from_host, sync, reps=12),
+              "note": "median wall time of blocking calls, device idle before each: latency = psa_set_sequences_device + "
+                      "psa_search (raw ASCII in HBM, one encode launch, ONE search launch); search_only = the sequences "
+                      "already set (another offset range, another mode); from_host_buffers = psa_set_sequences + psa_search"}
+    one = one_search()
     # ... and through the reference's own entry point gpu_run_program (a ProgramData struct in host memory)
-    legacy_ms = None
+    legacy_us = None
+    legacy_equal = True
     if rank == 0:
         import ctypes as C
         cap1, cap2 = n + 1, m + 1
@@ -402,32 +472,30 @@ def main():
         data = (C.c_char * len(blob)).from_buffer(blob)
         mutant = psa.Mutant()
         os.environ.setdefault("PSA_DEVICE", str(local_rank))
-        legacy = []
-        for k in range(7):
-            t0 = time.perf_counter()
-            score = psa.lib.gpu_run_program_layout(C.addressof(data), cap1, cap2, C.byref(mutant), lo1, hi1)
-            if k >= 2:
-                legacy.append(time.perf_counter() - t0)
-        legacy_equal = (mutant.offset, score) == (one.offset, one.score)
-        legacy_ms = 1e3 * sorted(legacy)[len(legacy) // 2]
-    # Kernels: HIP events recorded by the library on the stream it launches the kernel on.
-    # (1) the count kernel of a single search; (2) the dominant kernel of the timed region: in batch mode one
-    # launch of the batch count kernel serves several queries — timed alone (a batch of exactly one launch).
+        score = [0.0]
+
+        def legacy():
+            score[0] = psa.lib.gpu_run_program_layout(C.addressof(data), cap1, cap2, C.byref(mutant), lo1, hi1)
+        legacy_us = median_us(legacy, sync, reps=12)
+        legacy_equal = (mutant.offset, score[0]) == (one.offset, one.score)
+
+    # ---- kernels: HIP events recorded by the library on the stream it launches the kernel on ------------------
+    # (1) the one kernel of a single search; (2) the dominant kernel of the timed region: in batch mode one launch
+    # of the batch count kernel serves several queries — timed alone (a batch of exactly one launch).
+    ctx.set_sequences_device(p1, n, p2, m)
     ctx.set_profiling(True)
     for k in range(10):
-        ctx.set_seq1_device(t1.data_ptr(), n)
-        ctx.set_seq2_device(tq[0].data_ptr(), m)
         one = ctx.search(lo1, hi1)
     _, kernel_ms, profiled = ctx.profile_totals()
     _, single_kernel_name = ctx.last_timing(1)
     single_kernel_s = kernel_ms / max(profiled, 1) / 1e3
     kernel_name, kernel_s, kernel_queries = single_kernel_name, single_kernel_s, 1
-    if args.mode == "batch" and qhi - qlo >= 2:
+    if qhi - qlo >= 2:
         probe = min(qhi - qlo, PROFILE_LAUNCH_QUERIES)          # one launch of the batch kernel, as in the timed region
         times = []
         try:
             for k in range(6):
-                ctx.search_batch_device(tq[qlo].data_ptr(), probe, m, m)
+                ctx.search_batch_device(tq[qlo].data_ptr(), probe, m, m, lo1, hi1)
                 t_ms, name = ctx.last_timing(1)
                 if k >= 1:
                     times.append(t_ms)
@@ -439,7 +507,8 @@ def main():
     pairs_launch = (hi1 - lo1) * m * kernel_queries
     algorithmic_gbs = BYTES_PER_PAIR * pairs_launch / kernel_s / 1e9
 
-    # self-check (rank 0's query 0 is BASELINE.json configs[2]): committed oracle goldens, batch == single search
+    # ---- self-check (rank 0's query 0 is BASELINE.json configs[2]): committed oracle goldens, batch == single search,
+    # and the library's own health counters: a retried batch or a fallback inside the timed legs fails the run
     verified = None
     if rank == 0 and args.mode == "batch" and (n, m) == (1_000_000, 10_000) and qlo == 0:
         g_max, g_min = golden_case("c3_max"), golden_case("c3_min")
@@ -459,8 +528,67 @@ def main():
                     "batch_equals_single_search_queries": singles,
                     "batch_from_host_equals_batch": bool(from_host_equal),
                     "gpu_run_program_equals_psa_search": bool(legacy_equal),
+                    "duo_retries": ctx.duo_retry_count(),
+                    "reselects": ctx.reselect_count(),
                     "sequential_engine_fallbacks": ctx.fallback_count(),
+                    "second_launch_single_searches": ctx.unfused_count(),
                     "golden": "tests/golden/synthetic_golden.json c3_max / c3_min (CPU oracle, 48 s each)"}
+
+    # ---- extras (one GPU, rank 0): the other engine, the offset shard emulated, a low-entropy input -----------
+    sequential = shard_emulation = low_entropy = None
+    if extras and (n, m) == (1_000_000, 10_000):
+        # the literal north_star kernel: lane per offset, fp64 sum in the reference's order for EVERY offset
+        ctx.set_engine(psa.ENGINE_SEQUENTIAL)
+        ctx.set_sequences_device(p1, n, p2, m)
+        seq_res = ctx.search(0, total)
+        seq_us = median_us(lambda: ctx.search(0, total), sync, reps=8, warm=2)
+        ctx.set_engine(args.engine)
+        sequential = {"ms_per_search": seq_us / 1e3, "value": total * m / (seq_us * 1e-6), "unit": "char-pair scores/s",
+                      "equals_filter_engine": (seq_res.score, seq_res.offset, seq_res.char_offset, seq_res.ch) ==
+                                              (one.score, one.offset, one.char_offset, one.ch),
+                      "note": "PSA_ENGINE_SEQUENTIAL (psa_seq_kernel): every offset's fp64 sum in the reference's order, "
+                              "LDS pair-score table, wave-shuffle arg-best — the kernel north_star describes; the default "
+                              "filter engine returns the same bits"}
+        # One rank's share of an N-way offset shard (cpu_funcs.c:128-133) on this one GPU, no exchange: a blocking
+        # single search (sequences already on the device) and 64 searches in flight (psa_search_batch on the shard)
+        ctx.set_sequences_device(p1, n, p2, m)
+        nb = min(64, nq)
+        per_search, per_batch = {}, {}
+        for w in (1, 2, 4, 8):
+            lo_w, hi_w = psa.shard_range(total, w, 0)
+            per_search[str(w)] = median_us(lambda: ctx.search(lo_w, hi_w), sync, reps=16)
+            if nb >= 2:
+                ctx.set_seq1_device(p1, n)
+                per_batch[str(w)] = median_us(lambda: ctx.search_batch_device(tq.data_ptr(), nb, m, m, lo_w, hi_w), sync,
+                                              reps=5, warm=1) / 1e3
+                ctx.set_sequences_device(p1, n, p2, m)
+        shard_emulation = {
+            "blocking_search_us_per_rank": per_search,
+            "blocking_search_speedup_at_8": per_search["1"] / per_search["8"],
+            "batch_of_%d_ms_per_rank" % nb: per_batch,
+            "batch_speedup_at_8": (per_batch["1"] / per_batch["8"]) if per_batch else None,
+            "note": "rank 0's shard of an N-way split timed on ONE GPU (N = 1, 2, 4, 8), exchange not included: an "
+                    "emulation, not a scaling measurement.  A single 0.1 ms search is dominated by fixed costs (launch, plane "
+                    "build, epilogue, exact re-score) and cannot scale near-linearly; searches in flight do"}
+        # A plausible low-entropy workload: four-letter alphabet (far more near-ties than uniform A..Z)
+        rng = np.random.default_rng(4)
+        acgt = np.frombuffer(b"ACGT", np.uint8)
+        a1 = torch.from_numpy(rng.choice(acgt, n)).to(device)
+        a2 = torch.from_numpy(rng.choice(acgt, m)).to(device)
+        low_entropy = {}
+        for is_max in (True, False):
+            ctx.set_weights(WEIGHTS, is_max)
+            before = (ctx.fallback_count(), ctx.reselect_count(), ctx.unfused_count())
+            ctx.set_sequences_device(a1.data_ptr(), n, a2.data_ptr(), m)
+            r = ctx.search(0, total)
+            us = median_us(lambda: ctx.search(0, total), sync, reps=8, warm=1)
+            after = (ctx.fallback_count(), ctx.reselect_count(), ctx.unfused_count())
+            low_entropy["max" if is_max else "min"] = {
+                "search_only_us": us, "offset": r.offset, "score": r.score,
+                "fallbacks": after[0] - before[0], "reselects": after[1] - before[1], "second_launches": after[2] - before[2]}
+        low_entropy["note"] = ("|Seq1|=1M, |Seq2|=10k uniform over ACGT, README weights: same engine, counters = what the "
+                               "10 searches of the probe needed (tests/test_gpu_parity.py checks the answers against the oracle)")
+        ctx.set_weights(WEIGHTS, True)
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -469,11 +597,14 @@ def main():
 
     # The bound of the count kernels is VALU issue (bit-sliced counting out of LDS; HBM sees a few MB per launch):
     # wave-instructions per launch from the committed PMC profile (SQ_INSTS_VALU) over the live kernel time, against
-    # 1024 SIMDs x 1 wave64 instruction per 2 cycles at 2.4 GHz.
+    # 1024 SIMDs x 1 wave64 instruction per 2 cycles at 2.4 GHz.  Only if the profile is of THIS source.
     valu = None
+    valu_stale = None
     cpath = latest_profile("r*_counters.csv")
     if cpath:
         import csv
+        meta_path = cpath.replace("_counters.csv", "_meta.json")
+        meta = json.load(open(meta_path)) if os.path.exists(meta_path) else {}
         for row in csv.DictReader(open(cpath)):
             if row["counter"] == "SQ_INSTS_VALU" and kernel_name.split("<")[0] in row["kernel"] and \
                     (("<" not in kernel_name) or kernel_name in row["kernel"]) and "seq" not in os.path.basename(cpath):
@@ -483,6 +614,10 @@ def main():
                 valu = {"wave_instructions_per_launch": insts, "achieved_per_s": insts / kernel_s,
                         "source": os.path.relpath(cpath, ROOT)}
                 break
+        if valu and meta.get("csrc_sha256") != csrc_sha256():
+            valu_stale = (f"{os.path.relpath(cpath, ROOT)} was collected from other kernel sources (its "
+                          f"{os.path.basename(meta_path)} records csrc_sha256 {str(meta.get('csrc_sha256'))[:12]}, this tree is "
+                          f"{csrc_sha256()[:12]}): run tools/profile_round.sh")
 
     # Calibration of the achievable HBM bandwidth on this GPU: device-to-device copy of 1 GiB,
     # read + write counted.  Beside it, the kernel's MEASURED HBM rate = PMC traffic per launch / duration.
@@ -500,10 +635,13 @@ def main():
         copy_gbs = 10 * 2 * (1 << 30) / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
-    q0 = results[0] if (args.mode == "shard" or world > 1 or qlo == 0) else one
-    if valu:
+    q0 = results[0]
+    if valu and not valu_stale:
         roofline = {"bound": "valu", "achieved": valu["achieved_per_s"] / 1e9, "peak": VALU_PEAK / 1e9,
                     "unit": "G wave64-instructions/s", "frac": valu["achieved_per_s"] / VALU_PEAK}
+    elif valu:  # counters exist but belong to another build of the kernels: no fraction is better than a stale one
+        roofline = {"bound": "valu", "achieved": None, "peak": VALU_PEAK / 1e9, "unit": "G wave64-instructions/s",
+                    "frac": None, "frac_withheld": valu_stale}
     else:       # no committed PMC profile of this kernel: only the algorithmic-bytes model is available
         roofline = {"bound": "hbm", "achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": algorithmic_gbs / HBM_PEAK_GBS}
@@ -512,62 +650,76 @@ def main():
         "valu": dict(valu, peak_per_s=VALU_PEAK, note="peak = 1024 SIMDs x 2.4 GHz / 2 cycles per full-rate wave64 "
                      "instruction; instructions per launch from the committed rocprofv3 PMC pass.  75 % of the loop is "
                      "v_bitop3_b32, whose 8-byte encoding issues at 1.19 ns per SIMD at this occupancy (tools/ubench/ops3): "
-                     "the mix-specific ceiling is ~0.72 of this peak (DESIGN.md 4.4)") if valu else None,
+                     "the mix-specific ceiling is ~0.72 of this peak (DESIGN.md 4.4)") if valu and not valu_stale else None,
         "hbm_algorithmic": {"achieved": algorithmic_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "ratio_to_peak": algorithmic_gbs / HBM_PEAK_GBS,
                             "bytes_per_launch": BYTES_PER_PAIR * pairs_launch,
                             "note": "SURVEY.md 8(d) model, 2 B per char pair: NOT binding — tiles are reused from LDS, "
                                     "the kernel's physical HBM traffic is `traffic` bytes per launch"},
         "single_search_kernel": {"kernel": single_kernel_name, "kernel_ms": 1e3 * single_kernel_s,
+                                 "note": "one launch = one search: counts, candidates, exact re-score, fold, result tail",
                                  "hbm_algorithmic_GBps": BYTES_PER_PAIR * (hi1 - lo1) * m / single_kernel_s / 1e9},
         "measured_hbm_GBps": (traffic / kernel_s / 1e9) if traffic else None,
         "hbm_copy_calibration_GBps": copy_gbs})
+    if args.mode == "batch":
+        workload = (f"batch of {nq} independent searches per step and GPU: Seq2 queries (|Seq2|={m}, seeds "
+                    f"{SEED_QUERY0}..) vs one |Seq1|={n} (seed {SEED_SEQ1}), MAX, weights 1.5 2.6 0.3 0.2; "
+                    f"query 0 = BASELINE.json configs[2]; "
+                    + (f"{world} GPU(s) x {nq} queries (BASELINE.json configs[4] batch per GPU)" if weak or world == 1
+                       else f"{nq} queries dealt to {world} GPU(s) (BASELINE.json configs[4])"))
+    else:
+        workload = (f"{nq} search(es) |Seq1|={n} |Seq2|={m} MAX (BASELINE.json configs[2]/[3]) per step, offsets sharded "
+                    f"over {world} GPU(s)" + (", all in flight on every rank's shard (throughput mode)" if nq > 1 else ""))
     line = {
         "metric": "char-pair scores/sec (whole job), |Seq1|=1M |Seq2|=10k MAX searches",
         "value": value, "unit": "char-pair scores/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
+        "higher_is_better": True,
+        "scaling": "weak" if (weak or world == 1) else "strong", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": (f"batch of {nq} independent searches per step and GPU: Seq2 queries (|Seq2|={m}, seeds "
-                         f"{SEED_QUERY0}..) vs one |Seq1|={n} (seed {SEED_SEQ1}), MAX, weights 1.5 2.6 0.3 0.2; "
-                         f"query 0 = BASELINE.json configs[2]; "
-                         + (f"{world} GPU(s) x {nq} queries (BASELINE.json configs[4] batch per GPU)" if weak or world == 1
-                            else f"{nq} queries dealt to {world} GPU(s) (BASELINE.json configs[4])")
-                         if args.mode == "batch" else
-                         f"one search |Seq1|={n} |Seq2|={m} MAX (BASELINE.json configs[2]/[3]), offsets sharded "
-                         f"over {world} GPU(s)"),
-            "offsets_per_query": total, "queries_per_step": (total_q if args.mode == "batch" else 1),
+            "workload": workload,
+            "offsets_per_query": total, "queries_per_step": (total_q if args.mode == "batch" else nq),
             "pairs_per_step": pairs_step,
             "parallelism": (f"query-shard x{world}" if args.mode == "batch" else f"offset-shard x{world}"),
             "exchange": "none" if world == 1 else
                         ("1 RCCL all-reduce(sum) of one-hot int64 records per step" if args.backend == "nccl" else
                          "REHEARSAL: gloo all-reduce through host memory" + (", all ranks on one GPU" if args.share_gpu else "")),
-            "timed_region": "raw ASCII in HBM -> encode -> search -> records on host"},
+            "timed_region": "raw ASCII in HBM -> encode -> search -> records on host (timed_region_8d: the same from host buffers)"},
         "result_query0": {"offset": q0.offset, "char_offset": q0.char_offset,
                           "ch": chr(q0.ch) if q0.ch else "", "score": q0.score},
         "verified": verified,
-        "single_search_latency_ms": 1e3 * sorted(lat)[len(lat) // 2],
-        "single_search_latency_from_host_buffers_ms": 1e3 * sorted(host_lat)[len(host_lat) // 2],
-        "gpu_run_program_latency_ms": legacy_ms,
+        "single_search_latency_ms": single["latency_us"] / 1e3,
+        "single_search_latency_from_host_buffers_ms": single["from_host_buffers_us"] / 1e3,
+        "gpu_run_program_latency_ms": legacy_us / 1e3 if legacy_us else None,
+        "single_search": single,
         "roofline": roofline,
     }
+    if region_8d:
+        line["timed_region_8d"] = region_8d
+        line["batch_from_host"] = region_8d                      # (the name earlier rounds used)
     if minmax:
         line["minmax_batch"] = minmax
-    if from_host:
-        line["batch_from_host"] = from_host
+    if sequential:
+        line["sequential_engine"] = sequential
+    if shard_emulation:
+        line["shard_emulation"] = shard_emulation
+    if low_entropy:
+        line["low_entropy_acgt"] = low_entropy
     if emulated:
         line["config"]["emulated_world"] = args.emulate_world
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["cpu_baseline"] = cpu_baseline(s1.tobytes(), queries[0].tobytes(), total, m)
-        # the reference's own thread count (THREADS_COUNT, def.h:18)
-        line["cpu_baseline_4_threads"] = cpu_baseline(s1.tobytes(), queries[0].tobytes(), total, m, budget_s=4.0, threads=4)
+    if cpu:
+        line["cpu_baseline"] = cpu
+        line["cpu_baseline_4_threads"] = cpu4
     failed = False
     if verified is not None:
         failed = not (verified["query0_max_equals_golden"] and verified["query0_min_equals_golden"] and
                       verified["batch_equals_single_search_queries"] > 0 and verified["batch_from_host_equals_batch"] and
-                      verified["gpu_run_program_equals_psa_search"])
+                      verified["gpu_run_program_equals_psa_search"] and verified["duo_retries"] == 0 and
+                      verified["sequential_engine_fallbacks"] == 0)
+    if sequential and not sequential["equals_filter_engine"]:
+        failed = True
     if rank == 0:
         print(json.dumps(line), flush=True)
         if failed:

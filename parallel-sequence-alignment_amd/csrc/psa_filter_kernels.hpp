@@ -833,187 +833,319 @@ __device__ __forceinline__ double walk_sum(double s, const unsigned char* s_code
 }
 
 // ---- the same sum without walking: certified segments ---------------------------------
-// walk_sum is a chain of ~25 dependent wave steps (14 us for 10,000 chars).  Most of it can be known without walking.
+// walk_sum is a chain of ~30 dependent wave steps (14 us for 10,000 chars).  Most of it can be known without walking.
 // Let P_k be the exact (real-number) prefix sum after char k and s_k the reference's sequentially rounded one:
 // |s_k - P_k| <= slack for every k (the standard bound (k-1) u sum|p_i|; the host passes it doubled).  A char k is
 // INTERIOR when an order-free evaluation of P_{k-1} and P_k puts both at least `slack` inside the same binade
 // (2^e, 2^(e+1)) of the same sign, e large enough for the integer walk: then s_{k-1} and s_k certainly lie in that
 // binade, and the reference's addition fl(s_{k-1} + p_k) is the integer step S += R_e[class] (both multiples of
 // ulp_e, no tie — walk_sum's argument).  Every other char (a binade change, a prefix sum within slack of a power of
-// two, the first chars near zero) is a TRUE fp64 addition.  The classification is parallel work for the whole
-// workgroup (prefix class counts by a scan, one fp64 add and a few compares per char); what remains serial is one wave
-// walking the few true additions, with an interior run between two of them being cnt[class] x R_e[class] from the prefix
-// counts.  Nothing is assumed: a tie in a run's binade, a run that would leave its binade or too many true additions
-// send the candidate to walk_sum.
-constexpr int kCertMaxTrue = 384;         // true additions one wave takes before the walk is the better tool
+// two, the first chars near zero) is a TRUE fp64 addition.
+//   parallel (whole workgroup): prefix class counts by a block scan, one fp64 add and a few compares per char, the
+//     true additions' positions written out in order (a second scan);
+//   parallel (one lane per true addition): the interior run in front of it is cnt[class] x R_e[class] from the prefix
+//     counts, e known from the certificate;
+//   serial (one wave, scalar): the first 64 chars as a plain chain, then per true addition "mantissa += run's
+//     integer, rebuild, one fp64 add" — a dozen events instead of 10,000 additions.
+// Nothing is assumed: a tie in a run's binade, a state that is not in the certified binade, a run that leaves it or
+// too many true additions send the candidate to walk_sum.
+constexpr int kCertMaxTrue = 64;          // true additions (behind the first 64 chars) one wave applies; more: the walk
+constexpr int kCertMaxFail = 256;         // 16-char segments looked at char by char
+constexpr int kCertChain = 64;            // chars summed as a plain chain first (the sum is still near zero there)
+constexpr int kCertSeg = 16;              // chars per segment: one thread settles a segment, or one 16-lane row its chars
 
-struct CertLayout {                       // per candidate, in LDS behind its class codes
-    int chars_per_thread;                 // L: thread t classifies chars [t L, (t+1) L)
-    int nwords;                           // words of the true-addition bit mask
+struct CertEvent {                        // one true addition
+    int pos;                              // its char
+    int pad;
+    unsigned long long before;            // class counts of the chars in front of it, 16 bits per class
 };
+struct CertSeg {                          // a segment that needs the per-char test
+    int seg;
+    int pad;
+    unsigned long long before;            // class counts of the chars in front of the segment
+};
+struct CertList {                         // per candidate, in LDS behind its class codes
+    unsigned long long at_head;           // class counts of the first kCertChain chars
+    unsigned long long total;             // class counts of all m chars
+    int nfail, nev;
+    CertSeg   fail[kCertMaxFail];
+    CertEvent ev[kCertMaxTrue];           // positions >= kCertChain (certify_chars: any order; certified_sum sorts them)
+};
+__host__ __device__ inline int cert_bytes() { return ((int)sizeof(CertList) + 15) & ~15; }
 
-__host__ __device__ inline int cert_chars_per_thread(int m, int nthreads)
-{
-    return (((m + nthreads - 1) / nthreads) + 3) & ~3;
-}
-// bytes behind a candidate's codes: packed prefix counts per thread + the bit mask
-__host__ __device__ inline int cert_bytes(int m, int nthreads)
-{
-    return nthreads * 8 + (((m + 31) / 32 * 4 + 15) & ~15);
-}
-
-// Parallel part (every thread of the workgroup; contains workgroup barriers).  wbase[t] = class counts of the chars
-// in front of thread t's first char, 16 bits per class; bit k of nonint = char k takes a true addition;
-// *s_true = how many.  s_wsum: NT / 64 words of scratch.
 template <int NT>
-__device__ __forceinline__ void certify_chars(const unsigned char* s_codes, int m, const double* s_class, double slack,
-                                              int fast_min_exp, unsigned long long* wbase, unsigned* nonint,
-                                              unsigned long long* s_wsum, int* s_true, int tid)
+__device__ __forceinline__ unsigned long long block_scan_exclusive(unsigned long long v, unsigned long long* s_wsum, int tid,
+                                                                   unsigned long long* total)
 {
     const int lane = tid & 63, wave = tid >> 6;
-    const int L = cert_chars_per_thread(m, NT);
-    const int nwords = (m + 31) / 32;
-    for (int i = tid; i < nwords; i += NT) nonint[i] = 0u;
-    if (tid == 0) *s_true = 0;
-    const int k0 = tid * L;
-    const int k1 = k0 + L < m ? k0 + L : m;
-    unsigned long long local = 0ull;
-    for (int k = k0; k < k1; k += 4) {                 // (the codes behind m are class 4: counted nowhere)
-        const unsigned w = *reinterpret_cast<const unsigned*>(s_codes + k);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const unsigned cls = (w >> (8 * j)) & 7u;
-            if (cls < 4u) local += 1ull << (16 * cls);
-        }
-    }
-    const unsigned long long incl = (unsigned long long)wave_scan_inclusive((long long)local);
+    const unsigned long long incl = (unsigned long long)wave_scan_inclusive((long long)v);
+    __syncthreads();                                    // s_wsum is free again
     if (lane == 63) s_wsum[wave] = incl;
     __syncthreads();
-    unsigned long long base = incl - local;
-    for (int w = 0; w < wave; ++w) base += s_wsum[w];
-    wbase[tid] = base;
-    if (k0 < m) {
-        // order-free prefix sum in front of this thread's chars, then one addition per char (its own rounding is far
-        // inside the doubled slack)
-        double p = 0.0;
+    unsigned long long base = incl - v, all = 0ull;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) p += s_class[c] * (double)(unsigned)((base >> (16 * c)) & 0xffffull);
-        auto classify = [&](double x, unsigned& key, bool& safe) {
-            const unsigned long long b = (unsigned long long)__double_as_longlong(x);
-            key = (unsigned)(b >> 52);
-            const unsigned e = key & 0x7ffu;
-            const double a = __longlong_as_double((long long)(b & 0x7fffffffffffffffull));
-            const double lo = __longlong_as_double((long long)((unsigned long long)e << 52));
-            const double hi = __longlong_as_double((long long)((unsigned long long)(e + 1u) << 52));
-            safe = (int)e >= fast_min_exp && e < 0x7feu && a - lo >= slack && hi - a >= slack;
-        };
-        unsigned key_prev;
-        bool safe_prev;
-        classify(p, key_prev, safe_prev);
-        unsigned bits = 0u;
-        int ntrue = 0;
-        for (int k = k0; k < k1; ++k) {
-            p += s_class[s_codes[k] & 7u];
-            unsigned key;
-            bool safe;
-            classify(p, key, safe);
-            const bool interior = safe && safe_prev && key == key_prev;
-            if (!interior) { bits |= 1u << (k & 31); ++ntrue; }
-            key_prev = key;
-            safe_prev = safe;
-            if ((k & 31) == 31 || k == k1 - 1) {
-                if (bits) atomicOr(&nonint[k >> 5], bits);
-                bits = 0u;
+    for (int w = 0; w < NT / 64; ++w) {
+        const unsigned long long x = s_wsum[w];
+        if (w < wave) base += x;
+        all += x;
+    }
+    if (total) *total = all;
+    return base;
+}
+
+// scans inside the 16-lane rows of a wave (DPP row shifts; lanes without a source add nothing)
+template <int CTRL>
+__device__ __forceinline__ double row_add_f64(double v)
+{
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return v + __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned)lo));   // (+0.0 where no source)
+}
+__device__ __forceinline__ double row_scan_inclusive_f64(double v)
+{
+    v = row_add_f64<0x111>(v);
+    v = row_add_f64<0x112>(v);
+    v = row_add_f64<0x114>(v);
+    v = row_add_f64<0x118>(v);
+    return v;
+}
+__device__ __forceinline__ long long row_scan_inclusive_i64(long long v)
+{
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    return v;
+}
+
+// |x| at least `margin` inside its binade (2^e, 2^(e+1)), e in the integer walk's range?  With lo = 2^e:
+// min(|x| - lo, lo - (|x| - lo)) >= margin (both differences are exact).  hi32 = sign, exponent and upper mantissa.
+__device__ __forceinline__ bool cert_inside(double x, double margin, double amin, double amax, unsigned& hi32)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    hi32 = (unsigned)(b >> 32);
+    const double ax = __longlong_as_double((long long)(b & 0x7fffffffffffffffull));
+    const double lo = __longlong_as_double((long long)(b & 0x7ff0000000000000ull));
+    const double d = ax - lo;
+    return fmin(d, lo - d) >= margin && ax >= amin && ax < amax;
+}
+
+// order-free prefix sum from class counts (16 bits per class)
+__device__ __forceinline__ double cert_value(unsigned long long counts, const double* s_class)
+{
+    double p = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) p += s_class[c] * (double)(unsigned)((counts >> (16 * c)) & 0xffffull);
+    return p;
+}
+
+// Parallel part (every thread of the workgroup; contains workgroup barriers).  Level 1, a thread per 16-char segment:
+// every prefix sum of a segment lies within A = sum |p_i| of the sum in front of it, so if that sum is A + slack inside
+// its binade every char of the segment is interior — most segments.  Level 2, a 16-lane row per remaining segment, a
+// lane per char: the prefix sums by a row scan, the test per char, a true addition -> list->ev (any order) with the
+// class counts in front of it.  *s_true = how many, or more than kCertMaxTrue when a list overflowed.
+template <int NT>
+__device__ __forceinline__ void certify_chars(const unsigned char* s_codes, int m, const double* s_class, double slack,
+                                              int fast_min_exp, CertList* list, unsigned long long* s_wsum, int* s_true,
+                                              int tid)
+{
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nseg = (m + kCertSeg - 1) / kCertSeg;
+    const int per = (nseg + NT - 1) / NT;               // segments per thread (1 up to 16,384 chars with 1,024 threads)
+    const int seg0 = tid * per;
+    const double amin = __longlong_as_double((long long)((unsigned long long)(fast_min_exp < 1 ? 1 : fast_min_exp) << 52));
+    const double amax = __longlong_as_double(0x7fd0000000000000ll);
+    if (tid == 0) { list->nfail = 0; list->nev = 0; }
+    // class counts and reach of this thread's segments
+    auto segment = [&](int seg, unsigned long long& counts) {
+        counts = 0ull;
+        const int k0 = seg * kCertSeg;
+        if (k0 >= m) return;
+        const uint4 w4 = *reinterpret_cast<const uint4*>(s_codes + k0);     // (the codes behind m are class 4: counted nowhere)
+        const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned cls = (w[q] >> (8 * j)) & 7u;
+                if (cls < 4u) counts += 1ull << (16 * cls);
+            }
+    };
+    unsigned long long local = 0ull;
+    for (int s = 0; s < per; ++s) {
+        unsigned long long c;
+        segment(seg0 + s, c);
+        local += c;
+    }
+    unsigned long long all = 0ull;
+    unsigned long long before = block_scan_exclusive<NT>(local, s_wsum, tid, &all);     // (its barriers order nfail = 0)
+    if (tid == 0) list->total = all;
+    for (int s = 0; s < per; ++s) {
+        const int seg = seg0 + s;
+        unsigned long long c;
+        segment(seg, c);
+        const int k0 = seg * kCertSeg;
+        if (k0 == kCertChain) list->at_head = before;
+        if (k0 < m && k0 + kCertSeg > kCertChain) {
+            double reach = 0.0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) reach += fabs(s_class[q]) * (double)(unsigned)((c >> (16 * q)) & 0xffffull);
+            unsigned hi32;
+            if (!cert_inside(cert_value(before, s_class), reach * 1.0000001 + slack, amin, amax, hi32)) {
+                const int slot = atomicAdd(&list->nfail, 1);
+                if (slot < kCertMaxFail) {
+                    list->fail[slot].seg = seg;
+                    list->fail[slot].before = before;
+                }
             }
         }
-        if (ntrue) atomicAdd(s_true, ntrue);
+        before += c;
     }
+    __syncthreads();
+    const int nfail = list->nfail;
+    if (nfail <= kCertMaxFail) {
+        const int row = lane >> 4, col = lane & 15;
+        for (int f0 = wave * 4; f0 < nfail; f0 += (NT / 64) * 4) {
+            const int f = f0 + row;
+            const bool live = f < nfail;
+            const int k = (live ? list->fail[f].seg : 0) * kCertSeg + col;
+            const unsigned long long cb = live ? list->fail[f].before : 0ull;
+            const unsigned cls = s_codes[k] & 7u;
+            const double v = s_class[cls];                                           // (+0.0 behind m)
+            const double p_front = cert_value(cb, s_class);
+            const double p = p_front + row_scan_inclusive_f64(v);                    // after this lane's char
+            // the sum in front of this lane's char: the left neighbour's, the segment's own for the first lane
+            const long long pb = __double_as_longlong(p);
+            const int nlo = __builtin_amdgcn_update_dpp(0, (int)pb, 0x111, 0xf, 0xf, false);
+            const int nhi = __builtin_amdgcn_update_dpp(0, (int)(pb >> 32), 0x111, 0xf, 0xf, false);
+            const double p_prev = col == 0 ? p_front
+                                           : __longlong_as_double((long long)(((unsigned long long)(unsigned)nhi << 32) | (unsigned)nlo));
+            unsigned hi, hi_prev;
+            const bool safe = cert_inside(p, slack, amin, amax, hi);
+            const bool safe_prev = cert_inside(p_prev, slack, amin, amax, hi_prev);
+            const bool interior = safe && safe_prev && ((hi ^ hi_prev) >> 20) == 0u;   // same sign and exponent
+            const unsigned long long inc = cls < 4u ? 1ull << (16 * cls) : 0ull;
+            const unsigned long long cnt_before = cb + (unsigned long long)row_scan_inclusive_i64((long long)inc) - inc;
+            if (live && !interior && k >= kCertChain && k < m) {
+                const int slot = atomicAdd(&list->nev, 1);
+                if (slot < kCertMaxTrue) {
+                    list->ev[slot].pos = k;
+                    list->ev[slot].before = cnt_before;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid == 0) *s_true = nfail <= kCertMaxFail ? list->nev : kCertMaxTrue + 1;
     __syncthreads();
 }
 
 // Serial part: ONE wave (all 64 lanes, same arguments).  Returns false when the candidate has to be walked instead.
-template <int NT>
 __device__ __forceinline__ bool certified_sum(const unsigned char* s_codes, int m, const double* s_class,
-                                              const unsigned long long* wbase, const unsigned* nonint, int ntrue,
-                                              WalkScratch* ws, int lane, double& s_out)
+                                              CertList* list, int ntrue, WalkScratch* ws, int lane, double& s_out)
 {
     if (ntrue > kCertMaxTrue) return false;
-    const int L = cert_chars_per_thread(m, NT);
-    if (L > 64) return false;
-    const int nwords = (m + 31) / 32;
-    // class counts of the chars in front of char x (wave-uniform)
-    auto prefix = [&](int x) -> unsigned long long {
-        const int t = x > 0 ? (x - 1) / L : 0, r = x - t * L;          // (0 <= r <= L <= 64)
-        const unsigned cls = lane < r ? (unsigned)(s_codes[t * L + lane] & 7u) : 7u;
-        unsigned long long c = wbase[t];
-#pragma unroll
-        for (unsigned k = 0; k < 4u; ++k) c += (unsigned long long)__popcll(__ballot(cls == k)) << (16 * k);
-        return c;
-    };
-    double s = 0.0;
-    int k = 0;
-    bool failed = false;
-    // chars [k, upto) are interior: integer steps in the binade of s
-    auto run = [&](int upto) {
-        if (upto <= k || failed) return;
-        const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
-        const int e = (int)((sb >> 52) & 0x7ff);
-        long long r = 0;
-        bool tie = false;
-        if (lane < 4) {
-            const unsigned long long pb = (unsigned long long)__double_as_longlong(s_class[lane]);
-            const int ep = (int)((pb >> 52) & 0x7ff);
-            if (ep != 0) {
-                const unsigned long long mp = (pb & 0xfffffffffffffull) | (1ull << 52);
-                const int d = e - ep;
-                if (d < 2) tie = true;                   // (cannot happen for a certified binade: fast_min_exp)
-                else if (d <= 53) {
-                    const unsigned long long half = 1ull << (d - 1);
-                    tie = (mp & ((half << 1) - 1)) == half;
-                    const long long mag = (long long)((mp + half) >> d);
-                    r = (pb >> 63) ? -mag : mag;
-                }
-            }
-            ws->round[lane] = r;
+    static_assert(kCertMaxTrue == 64, "one lane per true addition");
+    // ---- the true additions in ascending order: every lane ranks its own entry, then all store back
+    {
+        const int pos = lane < ntrue ? list->ev[lane].pos : 0x7fffffff;
+        const unsigned long long before = lane < ntrue ? list->ev[lane].before : 0ull;
+        int rank = 0;
+        for (int j = 0; j < ntrue; ++j) rank += __builtin_amdgcn_readlane(pos, j) < pos ? 1 : 0;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < ntrue) {
+            list->ev[rank].pos = pos;
+            list->ev[rank].before = before;
         }
-        if (__ballot(tie) != 0ull) { failed = true; return; }
         __builtin_amdgcn_wave_barrier();
-        const unsigned long long cnt = prefix(upto) - prefix(k);      // per class, no borrows: the counts only grow
-        long long S = (long long)((sb & 0xfffffffffffffull) | (1ull << 52));
-        const bool neg = (sb >> 63) != 0;
-        if (neg) S = -S;
-        unsigned long long delta = 0ull;                              // (wraps; the certified total fits)
+    }
+    // ---- the first chars: plain chain (cpu_funcs.c:278), lanes past the end hold +0.0
+    const int head = m < kCertChain ? m : kCertChain;
+    ws->vals[lane] = lane < head ? s_class[s_codes[lane] & 7u] : 0.0;
+    __builtin_amdgcn_wave_barrier();
+    double s = 0.0;
+    {
+        const double2* v = reinterpret_cast<const double2*>(ws->vals);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) delta += ((cnt >> (16 * c)) & 0xffffull) * (unsigned long long)ws->round[c];
-        S += (long long)delta;
-        const long long bound_lo = neg ? -(1ll << 53) : (1ll << 52);
-        const long long bound_hi = neg ? -(1ll << 52) : (1ll << 53);
-        if (!((S > bound_lo) & (S < bound_hi))) { failed = true; return; }   // the certificate says this cannot happen
-        const unsigned long long mag = (unsigned long long)(S < 0 ? -S : S);
-        s = __longlong_as_double((long long)((neg ? (1ull << 63) : 0ull) | ((unsigned long long)e << 52) |
-                                             (mag & 0xfffffffffffffull)));
-        __builtin_amdgcn_wave_barrier();
-        k = upto;
-    };
-    for (int w0 = 0; w0 < nwords && !failed; w0 += 64) {
-        const unsigned mine = w0 + lane < nwords ? nonint[w0 + lane] : 0u;
-        unsigned long long lanes = __ballot(mine != 0u);
-        while (lanes && !failed) {
-            const int l = __ffsll((long long)lanes) - 1;
-            lanes &= lanes - 1;
-            unsigned word = (unsigned)__builtin_amdgcn_readlane((int)mine, l);
-            while (word && !failed) {
-                const int b = __ffs((int)word) - 1;
-                word &= word - 1;
-                const int at = (w0 + l) * 32 + b;
-                run(at);
-                if (failed) break;
-                s += s_class[s_codes[at] & 7u];           // the reference's own addition (cpu_funcs.c:278)
-                k = at + 1;
-            }
+        for (int l = 0; l < 32; ++l) {
+            const double2 x = v[l];
+            s += x.x;
+            s += x.y;
         }
     }
-    run(m);
+    __builtin_amdgcn_wave_barrier();
+    // ---- events: event i = the interior run behind the previous true addition (or the head) + true addition i;
+    // the last event (i == ntrue) is the run up to m alone.  One lane per event prepares it, then the wave applies
+    // the events in order.
+    bool failed = false;
+    for (int i0 = 0; i0 <= ntrue && !failed; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i <= ntrue;
+        unsigned long long delta = 0ull;
+        unsigned key = 0u;
+        bool bad = false;
+        double v = 0.0;
+        if (live) {
+            int at = m, from = head;
+            unsigned long long cb = list->total, ca = list->at_head;      // class counts in front of `at` / `from`
+            if (i < ntrue) {
+                at = list->ev[i].pos;
+                cb = list->ev[i].before;
+                v = s_class[s_codes[at] & 7u];
+            }
+            if (i > 0) {
+                const int prev = list->ev[i - 1].pos;
+                const unsigned cls = s_codes[prev] & 7u;
+                from = prev + 1;
+                ca = list->ev[i - 1].before + (cls < 4u ? 1ull << (16 * cls) : 0ull);
+            }
+            if (at > from) {
+                const unsigned long long cnt = cb - ca;                    // per class, no borrows: counts only grow
+                // the run's binade: the certified one of the sum in front of it
+                key = (unsigned)((unsigned long long)__double_as_longlong(cert_value(ca, s_class)) >> 52);
+                const int e = (int)(key & 0x7ffu);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const unsigned long long pb = (unsigned long long)__double_as_longlong(s_class[c]);
+                    const int ep = (int)((pb >> 52) & 0x7ff);
+                    long long r = 0;
+                    if (ep != 0) {
+                        const unsigned long long mp = (pb & 0xfffffffffffffull) | (1ull << 52);
+                        const int d = e - ep;
+                        if (d < 2) bad = true;                              // (not a certified binade: fast_min_exp)
+                        else if (d <= 53) {
+                            const unsigned long long half = 1ull << (d - 1);
+                            bad |= (mp & ((half << 1) - 1)) == half;        // a tie: the walk's business
+                            const long long mag = (long long)((mp + half) >> d);
+                            r = (pb >> 63) ? -mag : mag;
+                        }
+                    }
+                    delta += ((cnt >> (16 * c)) & 0xffffull) * (unsigned long long)r;   // (wraps; the certified total fits)
+                }
+                key |= 0x1000u;                                             // "has a run"
+            }
+        }
+        if (__ballot(bad) != 0ull) return false;
+        // Applied in order, straight-line: mantissa + the run's integer (0 without a run: the rebuild is the identity),
+        // the checks folded into one flag, then the reference's own addition (+0.0 behind the last true addition)
+        const int count = ntrue + 1 - i0 < 64 ? ntrue + 1 - i0 : 64;
+        bool ok = true;
+        for (int j = 0; j < count; ++j) {
+            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
+            const long long dj = readlane64((long long)delta, j);
+            const double vj = __longlong_as_double(readlane64(__double_as_longlong(v), j));
+            const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
+            const bool neg = (sb >> 63) != 0;
+            const long long M = (long long)((sb & 0xfffffffffffffull) | (1ull << 52));
+            const long long S = M + (neg ? -dj : dj);                        // |sum| in ulps of its binade
+            const bool run = (kj & 0x1000u) != 0u;
+            // the state is in the certified binade and the run stays strictly inside it (the certificate says both)
+            ok &= !run | (((unsigned)(sb >> 52) == (kj & 0xfffu)) & (S > (1ll << 52)) & (S < (1ll << 53)));
+            s = __longlong_as_double((long long)((sb & 0xfff0000000000000ull) | ((unsigned long long)S & 0xfffffffffffffull))) + vj;
+        }
+        failed = !ok;
+    }
     if (failed) return false;
     s_out = s;
     return true;
@@ -1073,6 +1205,14 @@ __device__ __forceinline__ double load_agent(const double* p)
                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+#ifdef PSA_PHASE_TIMING
+// debug build only: 100 MHz timestamps of the count kernel's phases, [block][phase]; rows 1000.. = re-score / tail
+__device__ unsigned long long g_phase_ts[1024][8];
+#define PSA_FPHASE(k) do { if (tid == 0) g_phase_ts[1002][k] = wall_clock64(); } while (0)
+#else
+#define PSA_FPHASE(k) do { } while (0)
+#endif
+
 // ---- end of a single search inside the count kernel ---------------------------------
 // Run by the last tile workgroup to arrive (all of its waves).  The candidate list is complete and the bound in
 // global_best final: candidates it rules out are dropped, the survivors (a handful) are re-scored in the reference's
@@ -1082,14 +1222,14 @@ __device__ __forceinline__ double load_agent(const double* p)
 constexpr int kFusedMax = 16;
 constexpr int kFusedWaves = 16;
 // LDS in front of the candidates' class codes (finish_search's carve-up) and how many candidates' codes fit at a time
-constexpr int kFusedFixedBytes = kRow * kRow + 8 * (int)sizeof(double) + kFusedWaves * (int)sizeof(WalkScratch) +
-                                 kFusedMax * kFusedWaves * 8 + kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4 + 16 +
-                                 kFusedWaves * 8 + kFusedMax * 4;
+constexpr int kFusedFixedBytes = 2 * kRow * kRow + (8 + kMaxRanks) * (int)sizeof(double) +
+                                 kFusedWaves * (int)sizeof(WalkScratch) + kFusedMax * kFusedWaves * 8 +
+                                 kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4 + 16 + kFusedWaves * 8 + kFusedMax * 4;
 // LDS of one candidate: its class codes + the walk's over-read, the certificate's prefix counts and bit mask
 __host__ __device__ inline int fused_codes_bytes(int m) { return (m + 64 * kRescoreEpl + 16 + 15) & ~15; }
 __host__ __device__ inline int fused_candidates_at_a_time(int lds_bytes, int m)
 {
-    const int region = fused_codes_bytes(m) + cert_bytes(m, kFusedWaves * 64);
+    const int region = fused_codes_bytes(m) + cert_bytes();
     const int g = (lds_bytes - kFusedFixedBytes) / region;
     return g > kFusedWaves ? kFusedWaves : g;
 }
@@ -1104,7 +1244,9 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* p = lds;
     unsigned char* s_clsrank = p;                                             p += kRow * kRow;
+    unsigned char* s_sub = p;                                                 p += kRow * kRow;
     double* s_class = reinterpret_cast<double*>(p);                           p += 8 * sizeof(double);
+    double* s_delta = reinterpret_cast<double*>(p);                           p += kMaxRanks * sizeof(double);
     WalkScratch* s_walk = reinterpret_cast<WalkScratch*>(p);                  p += WAVES * sizeof(WalkScratch);
     unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(p);    p += kFusedMax * WAVES * 8;   // [candidate of the round][wave]
     CandRec* s_rec = reinterpret_cast<CandRec*>(p);                           p += kFusedMax * sizeof(CandRec);
@@ -1115,11 +1257,31 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     unsigned char* s_codes = p;
     const int m = r.m;
     const int codes_bytes = fused_codes_bytes(m);
-    const int region = codes_bytes + cert_bytes(m, T);                       // per candidate: codes, prefix counts, bit mask
-    static_assert(WAVES == kFusedWaves, "kFusedFixedBytes is this carve-up for 16 waves");
+    const int region = codes_bytes + cert_bytes();                           // per candidate: codes, true-addition list
+    static_assert(WAVES == kFusedWaves && kMaxRanks == 16, "kFusedFixedBytes is this carve-up for 16 waves");
     const int G = fused_candidates_at_a_time(lds_bytes, m);                  // candidates classified at a time
 
+    PSA_FPHASE(0);
+    // ---- everything the tail reads from memory before it knows the survivors, in flight together: the search scalars,
+    // the whole candidate list (entries behind the count are never looked at) and the small tables
     const int count = load_agent(r.cand_count);
+    const unsigned long long best_key = load_agent(r.global_best);
+    double up[2];
+    int off[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int ci = tid + e * T;
+        up[e] = ci < r.cap ? load_agent(r.cand_upper + ci) : 0.0;
+        off[e] = ci < r.cap ? load_agent(r.cand + ci) : 0;
+    }
+    if (tid < kRow * kRow / 4) reinterpret_cast<unsigned*>(s_clsrank)[tid] = reinterpret_cast<const unsigned*>(r.clsrank)[tid];
+    else if (tid < kRow * kRow / 2) reinterpret_cast<unsigned*>(s_sub)[tid - kRow * kRow / 4] = reinterpret_cast<const unsigned*>(r.sub)[tid - kRow * kRow / 4];
+    else if (tid < kRow * kRow / 2 + kMaxRanks) s_delta[tid - kRow * kRow / 2] = r.delta_of_rank[tid - kRow * kRow / 2];
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s_class[k] = r.class_value[k];
+        s_n[0] = 0;
+    }
     if (count > r.cap) {
         // overflow against the running bound: the bound stays in global_best, the host selects once more against it
         if (tid == 0) {
@@ -1129,22 +1291,18 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         }
         return;
     }
-    for (int k = tid; k < kRow * kRow; k += T) s_clsrank[k] = r.clsrank[k];
-    if (tid == 0) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) s_class[k] = r.class_value[k];
-        s_n[0] = 0;
-    }
     __syncthreads();
-    const double final_best = key_order(load_agent(r.global_best));
-    for (int ci = tid; ci < count; ci += T)
-        if (load_agent(r.cand_upper + ci) >= final_best) {
+    const double final_best = key_order(best_key);
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+        if (tid + e * T < count && up[e] >= final_best) {
             const int k = atomicAdd(&s_n[0], 1);
-            if (k < kFusedMax) s_surv[k] = load_agent(r.cand + ci);
+            if (k < kFusedMax) s_surv[k] = off[e];
         }
     __syncthreads();
+    PSA_FPHASE(1);
     const int nsurv = s_n[0];
-    if (nsurv > kFusedMax || G < 1) {
+    if (nsurv > kFusedMax || G < 1 || r.cap > 2 * T) {
         if (tid == 0) {
             write_search_tail(r, nullptr, 2);
             store_agent(r.done, 0);                      // psa_rescore_kernel counts its own arrivals in it
@@ -1164,48 +1322,52 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
             if (lane == 0) s_keys[j * WAVES + wave] = key;
         }
         __syncthreads();
+        PSA_FPHASE(2);
         if (r.certify)
             for (int j = 0; j < cnt; ++j) {
                 unsigned char* mine = s_codes + (size_t)j * region;
                 certify_chars<T>(mine, m, s_class, r.walk_slack, r.fast_min_exp,
-                                 reinterpret_cast<unsigned long long*>(mine + codes_bytes),
-                                 reinterpret_cast<unsigned*>(mine + codes_bytes + T * 8), s_wsum, &s_true[j], tid);
+                                 reinterpret_cast<CertList*>(mine + codes_bytes), s_wsum, &s_true[j], tid);
             }
+        PSA_FPHASE(3);
         if (wave < cnt) {
             const int o = s_surv[base + wave];
-            const unsigned char* mine = s_codes + (size_t)wave * region;
-            WalkStats st = {0, 0, 0};
-            double s = 0.0;
-            if (!r.certify ||
-                !certified_sum<T>(mine, m, s_class, reinterpret_cast<const unsigned long long*>(mine + codes_bytes),
-                                  reinterpret_cast<const unsigned*>(mine + codes_bytes + T * 8), s_true[wave],
-                                  &s_walk[wave], lane, s))
-                s = walk_sum(0.0, mine, 0, m, s_class, &s_walk[wave], r.fast_ok, r.fast_min_exp, lane, st);
+            unsigned char* mine = s_codes + (size_t)wave * region;
+            // the best delta rank and its first char; the two symbols there are asked for now and used after the sum
             unsigned long long key = lane < WAVES ? s_keys[wave * WAVES + lane] : 0ull;
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
                 const unsigned long long other = __shfl_xor(key, d, 64);
                 key = other > key ? other : key;
             }
+            const int rank = (int)(key >> 32);
+            const int first_i = rank ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffu)) : 0;
+            const unsigned sym2 = r.s2[first_i], sym1 = r.s1[o + first_i];
+            WalkStats st = {0, 0, 0};
+            double s = 0.0;
+            if (!r.certify ||
+                !certified_sum(mine, m, s_class, reinterpret_cast<CertList*>(mine + codes_bytes), s_true[wave],
+                               &s_walk[wave], lane, s))
+                s = walk_sum(0.0, mine, 0, m, s_class, &s_walk[wave], r.fast_ok, r.fast_min_exp, lane, st);
             if (lane == 0) {
-                const int rank = (int)(key >> 32);
                 CandRec c;
                 c.offset = o;
                 c.rank = rank;
                 if (rank) {
-                    const int i = (int)(0xffffffffu - (unsigned)(key & 0xffffffffu));
-                    c.score = s + r.delta_of_rank[rank];
-                    c.char_offset = i;
-                    c.ch = r.sub[(unsigned)r.s2[i] * kRow + r.s1[o + i]];
+                    c.score = s + s_delta[rank];
+                    c.char_offset = first_i;
+                    c.ch = s_sub[sym2 * kRow + sym1];
                 } else {
-                    c.score = r.delta_of_rank[0];
+                    c.score = s_delta[0];
                     c.char_offset = -1;
                     c.ch = 0;
                 }
                 s_rec[base + wave] = c;
             }
         }
+        PSA_FPHASE(4);
         __syncthreads();
+        PSA_FPHASE(5);
     }
     if (tid == 0) {
         const bool is_max = r.is_max != 0;
@@ -1225,6 +1387,10 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         store_agent(r.done, 0);
         __hip_atomic_store(r.global_best, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    PSA_FPHASE(6);
+#ifdef PSA_PHASE_TIMING
+    if (tid == 0) { g_phase_ts[1003][0] = (unsigned long long)count; g_phase_ts[1003][1] = (unsigned long long)nsurv; g_phase_ts[1003][2] = (unsigned long long)s_true[0]; }
+#endif
 }
 
 // ---- count kernel --------------------------------------------------------------
@@ -1263,8 +1429,6 @@ struct CountArgs {
 };
 
 #ifdef PSA_PHASE_TIMING
-// debug build only: 100 MHz timestamps of the count kernel's phases, [block][phase]
-__device__ unsigned long long g_phase_ts[1024][8];
 #define PSA_PHASE(k) do { if (tid == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1000) g_phase_ts[blockIdx.y * gridDim.x + blockIdx.x][k] = wall_clock64(); } while (0)
 #else
 #define PSA_PHASE(k) do { } while (0)
@@ -1351,12 +1515,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     // registers, two 16-bit counts per dword) and adds them to the tile's cells in LDS (ds_add_u32);
     // each thread then picks up the counts of its offsets.
     PSA_PHASE(2);
-    // the running best bound of every mode, asked for now and used after the barrier (the selection below only needs
-    // A lower bound of the final best: a value a few microseconds old is as good)
-    unsigned long long running[2];
-#pragma unroll
-    for (int mode = 0; mode < 2; ++mode)
-        running[mode] = a.inline_select && mode < a.nmodes ? load_agent(a.sel[mode].global_best) : 0ull;
     add_counts_to_cells(cnt, cells, kTileWords, lane, true);
     PSA_PHASE(3);
     PSA_PHASE(4);
@@ -1409,7 +1567,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     }
     // the counts are final
     PSA_PHASE(5);
-    __shared__ unsigned long long s_best[2][WAVES];
+    __shared__ unsigned long long s_best[2][WAVES + 1];
     double up[2][kPer];
     for (int mode = 0; mode < a.nmodes; ++mode) {
         // offsets relative to the range's first one; the tile answers for its first kTileStride positions
@@ -1424,20 +1582,18 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         if (lane == 0) s_best[mode][wave] = key;
     }
     __syncthreads();
+    if (tid < a.nmodes) {
+        // running best over the tiles finished so far: a lower bound of the final best, so selecting against it
+        // keeps a superset of the true candidates (whoever re-scores re-checks against the final bound)
+        unsigned long long key = s_best[tid][0];
+        for (int w = 1; w < WAVES; ++w) key = s_best[tid][w] > key ? s_best[tid][w] : key;
+        const unsigned long long old = atomicMax(a.sel[tid].global_best, key);
+        s_best[tid][WAVES] = old > key ? old : key;
+    }
+    __syncthreads();
     for (int mode = 0; mode < a.nmodes; ++mode) {
         const CountArgs::CountSelect& sel = a.sel[mode];
-        unsigned long long key = s_best[mode][lane & (WAVES - 1)];            // the tile's best pessimistic bound
-#pragma unroll
-        for (int d = WAVES / 2; d >= 1; d >>= 1) {
-            const unsigned long long other = __shfl_xor(key, d, 64);
-            key = other > key ? other : key;
-        }
-        // Candidates = offsets whose optimistic bound reaches the best pessimistic bound known: the tile's own and the
-        // running best over the tiles that finished earlier — a lower bound of the final best, so this keeps a
-        // superset of the true candidates (whoever re-scores re-checks against the final bound).
-        if (tid == 0) atomicMax(sel.global_best, key);                        // (no return value: nobody waits for it)
-        const unsigned long long need_key = mode == 0 ? running[0] : running[1];
-        const double need = key_order(need_key > key ? need_key : key);
+        const double need = key_order(s_best[mode][WAVES]);
 #pragma unroll
         for (int e = 0; e < kPer; ++e)
             if (up[mode][e] >= need) {
@@ -1692,8 +1848,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     __shared__ double             s_class[8];     // the class values, indexable (a by-value kernel argument indexed
                                                   // at run time would be copied to scratch by every lane)
     __shared__ unsigned long long s_key[kRescoreThreads / 64];
-    __shared__ unsigned long long s_wbase[kRescoreThreads];                     // certified_sum: prefix class counts ...
-    __shared__ unsigned           s_nonint[(kRescoreChunk + 31) / 32];          // ... and the true-addition bit mask
+    __shared__ CertList           s_cert;                                       // certified_sum: the true additions
     __shared__ unsigned long long s_wsum[kRescoreThreads / 64];
     __shared__ int s_true;
     __shared__ int s_last;
@@ -1760,10 +1915,10 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
         if (ci == (int)blockIdx.x) PSA_RPHASE(2);
         // ---- sum the chunk in reference order (wave 0): certified segments when the whole Seq2 is staged, else the walk
         const bool certify = a.certify && m <= kRescoreChunk;
-        if (certify) certify_chars<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, s_wbase, s_nonint,
+        if (certify) certify_chars<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, &s_cert,
                                                     s_wsum, &s_true, tid);
         if (tid < 64) {
-            if (!certify || !certified_sum<kRescoreThreads>(s_codes, m, s_class, s_wbase, s_nonint, s_true, &s_walk, lane, s)) {
+            if (!certify || !certified_sum(s_codes, m, s_class, &s_cert, s_true, &s_walk, lane, s)) {
                 st.left += 1000;                        // (phase-timing builds: the walk was needed)
                 s = walk_sum(s, s_codes, c0, c1, s_class, &s_walk, a.fast_ok, a.fast_min_exp, lane, st);
             }

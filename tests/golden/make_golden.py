@@ -34,19 +34,36 @@ FULL = [
     ("c3_max", 1002, 2002, 1000000, 10000, W_README, True),   # BASELINE.json configs[2]
     ("c3_min", 1002, 2002, 1000000, 10000, W_README, False),
 ]
+# --acgt: a plausible low-entropy workload at full size: four-letter alphabet (numpy default_rng(4).choice over b"ACGT",
+# Seq1 first, then Seq2 — the same draw bench.py's `low_entropy_acgt` leg and the GPU test make)
+ACGT = [
+    ("acgt_max", None, None, 1000000, 10000, W_README, True),
+    ("acgt_min", None, None, 1000000, 10000, W_README, False),
+]
+
+
+def acgt_pair(n, m):
+    import numpy as np
+    rng = np.random.default_rng(4)
+    ab = np.frombuffer(b"ACGT", np.uint8)
+    return rng.choice(ab, n).tobytes(), rng.choice(ab, m).tobytes()
 
 
 def main():
     out_path = os.path.join(ROOT, "tests", "golden", "synthetic_golden.json")
-    cases = CASES + (FULL if "--full" in sys.argv else [])
+    cases = (CASES if "--acgt" not in sys.argv else []) + (FULL if "--full" in sys.argv else []) + \
+            (ACGT if "--acgt" in sys.argv else [])
     old = {}
     if os.path.exists(out_path):
         old = {c["name"]: c for c in json.load(open(out_path))["cases"]}
     done = []
     threads = os.cpu_count() or 1
     for name, seed1, seed2, n, m, w, is_max in cases:
-        s1 = psa_amd.generate_sequence(seed1, n)
-        s2 = psa_amd.generate_sequence(seed2, m)
+        if seed1 is None:
+            s1, s2 = acgt_pair(n, m)
+        else:
+            s1 = psa_amd.generate_sequence(seed1, n)
+            s2 = psa_amd.generate_sequence(seed2, m)
         t0 = time.time()
         score, off, ci, ch = oracle.search(s1, s2, w, is_max, threads=threads)
         dt = time.time() - t0

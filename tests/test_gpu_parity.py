@@ -797,6 +797,36 @@ def test_rescore_fallbacks_are_bit_exact(psa_debug, oracle, monkeypatch, knob):
                 assert_same(c.search(), oracle.search(s1, s2, w, is_max, threads=4))
 
 
+def test_low_entropy_full_size_four_letter_alphabet(psa):
+    """a plausible low-entropy input at the headline size — |Seq1| = 1M, |Seq2| = 10k uniform over ACGT,
+    README weights, MAX and MIN — against committed CPU-oracle goldens (tests/golden/make_golden.py --acgt, 60 s and
+    196 s of 8 threads).  Far more near-ties than uniform A..Z (a quarter of the pairs are '*', most of the rest share
+    one score): the answers are the oracle's, and the search stays on the filter engine (no sequential-engine fallback;
+    the ordering contract is cuda_funcs.cu:290-307 / cpu_funcs.c:287-294)."""
+    gold = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))["cases"]}
+    rng = np.random.default_rng(4)
+    ab = np.frombuffer(b"ACGT", np.uint8)
+    s1, s2 = rng.choice(ab, 1_000_000).tobytes(), rng.choice(ab, 10_000).tobytes()
+    with psa.Context(0) as c:
+        for is_max, name in ((True, "acgt_max"), (False, "acgt_min")):
+            g = gold[name]
+            c.set_weights(W_README, is_max)
+            c.set_sequences(s1, s2)
+            for engine in (psa.ENGINE_AUTO, psa.ENGINE_FILTER):
+                c.set_engine(engine)
+                r = c.search()
+                assert (r.offset, r.char_offset, chr(r.ch), "%.17g" % r.score) == (g["offset"], g["char_offset"], g["ch"], g["score"]), name
+        assert c.fallback_count() == 0
+        # a batch of such queries (the first is Seq2 itself)
+        qs = [s2] + [rng.choice(ab, 10_000).tobytes() for _ in range(3)]
+        c.set_weights(W_README, True)
+        hi, lo = c.search_batch_minmax(qs)
+        for r, name in ((hi[0], "acgt_max"), (lo[0], "acgt_min")):
+            g = gold[name]
+            assert (r.offset, r.char_offset, chr(r.ch), "%.17g" % r.score) == (g["offset"], g["char_offset"], g["ch"], g["score"]), name
+        assert c.fallback_count() == 0 and c.duo_retry_count() == 0
+
+
 def test_batch_matches_oracle_and_single_searches(psa, oracle):
     """psa_search_batch: per-query results == oracle (small) and == psa_search (1M x 10k), both engines,
     including a query whose candidate list overflows (falls back inside the batch)."""

@@ -8,6 +8,7 @@ reads  gpurun_out/<prefix>_stats/      rocprofv3 --kernel-trace --stats  (bench.
 writes profiles/<tag>_kernel_stats.csv, profiles/<tag>_twin_kernel_stats.csv (verbatim rocprofv3 summaries),
        profiles/<tag>_counters.csv   (kernel, counter, dispatches, mean_per_dispatch — every (kernel, counter) pair
                                       from its own rows of its own pass),
+       profiles/<tag>_meta.json      (sha256 of the kernel sources the passes ran: bench.py checks it),
 and updates profiles/hbm_traffic.json (per-launch HBM bytes of each psa kernel:
        (2 x FETCH_SIZE + WRITE_SIZE) x 1024 — FETCH_SIZE/WRITE_SIZE are in KiB and gfx950's FETCH_SIZE
        reports half of the fetched bytes, MI355X_MICROARCH.md §HBM; the x2 is calibrated there for
@@ -20,6 +21,7 @@ import json
 import os
 import shutil
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "profiles")
@@ -55,6 +57,14 @@ def main():
         traffic[short] = (2 * sum(fetch) / len(fetch) + sum(write) / len(write)) * 1024
     json.dump(traffic, open(tpath, "w"), indent=1, sort_keys=True)
     print(json.dumps(traffic, indent=1))
+    # what these summaries are evidence for: the kernel sources they were collected from (bench.py withholds
+    # roofline.frac when the tree's hash differs), and the per-kernel resources of that build
+    sys.path.insert(0, ROOT)
+    import bench
+    meta = {"csrc_sha256": bench.csrc_sha256(), "collected": time.strftime("%Y-%m-%d %H:%M:%S UTC", time.gmtime()),
+            "commands": "tools/profile_round.sh " + tag}
+    json.dump(meta, open(os.path.join(OUT, f"{tag}_meta.json"), "w"), indent=1)
+    print(json.dumps(meta, indent=1))
 
 
 if __name__ == "__main__":

@@ -42,6 +42,15 @@ for row in tail:     # the workgroup that finished the search (finish_search)
     print(f"fused tail (last tile workgroup): select end -> tail written {(row[7] - row[6]) / 100.0:.2f} us; "
           f"kernel start -> end {(row[7] - t0) / 100.0:.2f} us")
 
+full = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
+ft, fc = full[1002], full[1003]
+names = ["arrival -> count + lists filtered", "tables + classify (all waves)", "certificate (all waves)",
+         "sum (one wave per survivor)", "barrier", "fold + tail"]
+print(f"fused tail of the last search: {fc[0]} candidates listed, {fc[1]} survive the final bound, {fc[2]} true additions "
+      f"behind the first 64 chars of survivor 0")
+for k, name in enumerate(names):
+    print(f"tail {name:36s} {(ft[k + 1] - ft[k]) / 100.0:7.2f} us")
+
 # re-score kernel (workgroup 0, its first candidate)
 ctx.debug_rescore(np.array([r.offset, 5, 77777], dtype=np.int32))
 assert lib.psa_debug_phase_ts(buf) == 0

@@ -45,7 +45,7 @@ with psa.Context(0) as cf, psa.Context(0) as cs, psa.Context(0) as ca:      # ca
         cf.set_seq2(qs[-1])
         single = cf.search(first, last)
         assert key(single) == key(one[-1]), ("single vs batch", n, m, nq, w, first, last)
-        ca.set_seq2(qs[-1])
+        ca.set_sequences(s1, qs[-1])                        # both sequences by one encode launch
         assert key(ca.search(first, last)) == key(single), ("auto engine", n, m, nq, w, first, last)
         assert [key(r) for r in one] == [key(r) for r in hi], ("batch vs minmax", n, m, nq, w, first, last)
         for mode, got in ((True, hi), (False, lo)):
@@ -57,4 +57,7 @@ with psa.Context(0) as cf, psa.Context(0) as cs, psa.Context(0) as ca:      # ca
         if time.time() > t_note:                      # a sign of life every minute (long silent runs get killed)
             print(f"soak: {cases} cases so far", flush=True)
             t_note = time.time() + 60.0
-    print(f"soak: {cases} random cases ok, {cf.fallback_count()} filter fallbacks (ties), {cf.reselect_count()} reselects")
+    print(f"soak: {cases} random cases ok; filter context: {cf.fallback_count()} sequential-engine fallbacks (ties), "
+          f"{cf.reselect_count()} reselects, {cf.unfused_count()} second launches (> 16 survivors or a long Seq2), "
+          f"{cf.duo_retry_count()} retried batches (a group barrier gave up: expected 0)")
+    assert cf.duo_retry_count() == 0 and ca.duo_retry_count() == 0
