@@ -85,6 +85,8 @@ def test_synthetic_golden(ctx, psa):
     BASELINE.json sizes (100k x 1k and 1M x 10k, both modes)."""
     gold = json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))
     for case in gold["cases"]:
+        if case["seed1"] is None:
+            continue                    # the ACGT cases have a numpy draw, not the library's generator: their own test
         s1 = psa.generate_sequence(case["seed1"], case["n"])
         s2 = psa.generate_sequence(case["seed2"], case["m"])
         res = run(ctx, s1, s2, case["weights"], case["is_max"])
@@ -712,6 +714,8 @@ def test_filter_engine_synthetic_golden_and_ranges(psa, oracle):
     with psa.Context(0) as c:
         c.set_engine(psa.ENGINE_FILTER)
         for case in gold["cases"]:
+            if case["seed1"] is None:
+                continue                # (the ACGT cases: test_low_entropy_full_size_four_letter_alphabet)
             s1 = psa.generate_sequence(case["seed1"], case["n"])
             s2 = psa.generate_sequence(case["seed2"], case["m"])
             res = run(c, s1, s2, case["weights"], case["is_max"])
