@@ -879,8 +879,7 @@ __device__ __forceinline__ unsigned long long block_scan_exclusive(unsigned long
 {
     const int lane = tid & 63, wave = tid >> 6;
     const unsigned long long incl = (unsigned long long)wave_scan_inclusive((long long)v);
-    __syncthreads();                                    // s_wsum is free again
-    if (lane == 63) s_wsum[wave] = incl;
+    if (lane == 63) s_wsum[wave] = incl;                // (s_wsum is free: every caller ends behind a barrier)
     __syncthreads();
     unsigned long long base = incl - v, all = 0ull;
 #pragma unroll
@@ -944,11 +943,10 @@ __device__ __forceinline__ double cert_value(unsigned long long counts, const do
 // every prefix sum of a segment lies within A = sum |p_i| of the sum in front of it, so if that sum is A + slack inside
 // its binade every char of the segment is interior — most segments.  Level 2, a 16-lane row per remaining segment, a
 // lane per char: the prefix sums by a row scan, the test per char, a true addition -> list->ev (any order) with the
-// class counts in front of it.  *s_true = how many, or more than kCertMaxTrue when a list overflowed.
+// class counts in front of it (cert_true_additions: how many).
 template <int NT>
 __device__ __forceinline__ void certify_chars(const unsigned char* s_codes, int m, const double* s_class, double slack,
-                                              int fast_min_exp, CertList* list, unsigned long long* s_wsum, int* s_true,
-                                              int tid)
+                                              int fast_min_exp, CertList* list, unsigned long long* s_wsum, int tid)
 {
     const int lane = tid & 63, wave = tid >> 6;
     const int nseg = (m + kCertSeg - 1) / kCertSeg;
@@ -979,12 +977,12 @@ __device__ __forceinline__ void certify_chars(const unsigned char* s_codes, int 
         local += c;
     }
     unsigned long long all = 0ull;
-    unsigned long long before = block_scan_exclusive<NT>(local, s_wsum, tid, &all);     // (its barriers order nfail = 0)
+    unsigned long long before = block_scan_exclusive<NT>(local, s_wsum, tid, &all);     // (its barrier orders nfail = 0)
     if (tid == 0) list->total = all;
     for (int s = 0; s < per; ++s) {
         const int seg = seg0 + s;
-        unsigned long long c;
-        segment(seg, c);
+        unsigned long long c = local;
+        if (per > 1) segment(seg, c);
         const int k0 = seg * kCertSeg;
         if (k0 == kCertChain) list->at_head = before;
         if (k0 < m && k0 + kCertSeg > kCertChain) {
@@ -1037,8 +1035,12 @@ __device__ __forceinline__ void certify_chars(const unsigned char* s_codes, int 
         }
     }
     __syncthreads();
-    if (tid == 0) *s_true = nfail <= kCertMaxFail ? list->nev : kCertMaxTrue + 1;
-    __syncthreads();
+}
+
+// how many true additions certify_chars found (more than kCertMaxTrue: a list overflowed, walk instead)
+__device__ __forceinline__ int cert_true_additions(const CertList* list)
+{
+    return list->nfail <= kCertMaxFail ? list->nev : kCertMaxTrue + 1;
 }
 
 // Serial part: ONE wave (all 64 lanes, same arguments).  Returns false when the candidate has to be walked instead.
@@ -1224,7 +1226,7 @@ constexpr int kFusedWaves = 16;
 // LDS in front of the candidates' class codes (finish_search's carve-up) and how many candidates' codes fit at a time
 constexpr int kFusedFixedBytes = 2 * kRow * kRow + (8 + kMaxRanks) * (int)sizeof(double) +
                                  kFusedWaves * (int)sizeof(WalkScratch) + kFusedMax * kFusedWaves * 8 +
-                                 kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4 + 16 + kFusedWaves * 8 + kFusedMax * 4;
+                                 kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4 + 16 + kFusedWaves * 8;
 // LDS of one candidate: its class codes + the walk's over-read, the certificate's prefix counts and bit mask
 __host__ __device__ inline int fused_codes_bytes(int m) { return (m + 64 * kRescoreEpl + 16 + 15) & ~15; }
 __host__ __device__ inline int fused_candidates_at_a_time(int lds_bytes, int m)
@@ -1253,7 +1255,6 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     int* s_surv = reinterpret_cast<int*>(p);                                  p += kFusedMax * 4;
     int* s_n = reinterpret_cast<int*>(p);                                     p += 16;
     unsigned long long* s_wsum = reinterpret_cast<unsigned long long*>(p);    p += WAVES * 8;
-    int* s_true = reinterpret_cast<int*>(p);                                  p += kFusedMax * 4;
     unsigned char* s_codes = p;
     const int m = r.m;
     const int codes_bytes = fused_codes_bytes(m);
@@ -1327,7 +1328,7 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
             for (int j = 0; j < cnt; ++j) {
                 unsigned char* mine = s_codes + (size_t)j * region;
                 certify_chars<T>(mine, m, s_class, r.walk_slack, r.fast_min_exp,
-                                 reinterpret_cast<CertList*>(mine + codes_bytes), s_wsum, &s_true[j], tid);
+                                 reinterpret_cast<CertList*>(mine + codes_bytes), s_wsum, tid);
             }
         PSA_FPHASE(3);
         if (wave < cnt) {
@@ -1346,8 +1347,8 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
             WalkStats st = {0, 0, 0};
             double s = 0.0;
             if (!r.certify ||
-                !certified_sum(mine, m, s_class, reinterpret_cast<CertList*>(mine + codes_bytes), s_true[wave],
-                               &s_walk[wave], lane, s))
+                !certified_sum(mine, m, s_class, reinterpret_cast<CertList*>(mine + codes_bytes),
+                               cert_true_additions(reinterpret_cast<const CertList*>(mine + codes_bytes)), &s_walk[wave], lane, s))
                 s = walk_sum(0.0, mine, 0, m, s_class, &s_walk[wave], r.fast_ok, r.fast_min_exp, lane, st);
             if (lane == 0) {
                 CandRec c;
@@ -1389,7 +1390,7 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     }
     PSA_FPHASE(6);
 #ifdef PSA_PHASE_TIMING
-    if (tid == 0) { g_phase_ts[1003][0] = (unsigned long long)count; g_phase_ts[1003][1] = (unsigned long long)nsurv; g_phase_ts[1003][2] = (unsigned long long)s_true[0]; }
+    if (tid == 0) { g_phase_ts[1003][0] = (unsigned long long)count; g_phase_ts[1003][1] = (unsigned long long)nsurv; g_phase_ts[1003][2] = (unsigned long long)reinterpret_cast<const CertList*>(s_codes + codes_bytes)->nev; }
 #endif
 }
 
@@ -1850,7 +1851,6 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     __shared__ unsigned long long s_key[kRescoreThreads / 64];
     __shared__ CertList           s_cert;                                       // certified_sum: the true additions
     __shared__ unsigned long long s_wsum[kRescoreThreads / 64];
-    __shared__ int s_true;
     __shared__ int s_last;
     extern __shared__ unsigned char s_pad[];      // never touched: only makes the workgroup too big to share a
     (void)s_pad;                                  // CU with a count-kernel workgroup (LDS), see launch site
@@ -1915,10 +1915,9 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
         if (ci == (int)blockIdx.x) PSA_RPHASE(2);
         // ---- sum the chunk in reference order (wave 0): certified segments when the whole Seq2 is staged, else the walk
         const bool certify = a.certify && m <= kRescoreChunk;
-        if (certify) certify_chars<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, &s_cert,
-                                                    s_wsum, &s_true, tid);
+        if (certify) certify_chars<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, &s_cert, s_wsum, tid);
         if (tid < 64) {
-            if (!certify || !certified_sum(s_codes, m, s_class, &s_cert, s_true, &s_walk, lane, s)) {
+            if (!certify || !certified_sum(s_codes, m, s_class, &s_cert, cert_true_additions(&s_cert), &s_walk, lane, s)) {
                 st.left += 1000;                        // (phase-timing builds: the walk was needed)
                 s = walk_sum(s, s_codes, c0, c1, s_class, &s_walk, a.fast_ok, a.fast_min_exp, lane, st);
             }
