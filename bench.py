@@ -353,8 +353,7 @@ def main():
 
         def step():
             if nq == 1:
-                ctx.set_sequences_device(t1.data_ptr(), n, tq[0].data_ptr(), m)
-                recs = [ctx.search(first, last)]
+                recs = [ctx.search_device(t1.data_ptr(), n, tq[0].data_ptr(), m, first, last)]
             else:                                                 # throughput mode: nq queries in flight on this shard
                 ctx.set_seq1_device(t1.data_ptr(), n)
                 recs = ctx.search_batch_device(tq.data_ptr(), nq, m, m, first, last)
@@ -437,7 +436,10 @@ def main():
     h2 = hq_all[0]
     p1, p2 = t1.data_ptr(), tq[0].data_ptr()
 
-    def one_search():                       # raw ASCII in HBM -> best mutant on the host: one encode launch + one search launch
+    def one_search():                       # raw ASCII in HBM -> best mutant on the host: ONE launch
+        return ctx.search_device(p1, n, p2, m, lo1, hi1)
+
+    def one_search_encode_first():          # the same as an encode launch + a search launch
         ctx.set_sequences_device(p1, n, p2, m)
         return ctx.search(lo1, hi1)
 
@@ -451,12 +453,17 @@ def main():
         return ctx.search(lo1, hi1)
 
     single = {"latency_us": median_us(one_search, sync),
-              "two_setters_us": median_us(one_search_two_setters, sync, reps=12),
+              "encode_launch_first_us": median_us(one_search_encode_first, sync, reps=12),
+              "two_setters_us": median_us(one_search_two_setters, sync, reps=12)}
+    ctx.set_sequences_device(p1, n, p2, m)
+    single.update({
               "search_only_us": median_us(lambda: ctx.search(lo1, hi1), sync),
               "from_host_buffers_us": median_us(one_search_from_host, sync, reps=12),
-              "note": "median wall time of blocking calls, device idle before each: latency = psa_set_sequences_device + "
-                      "psa_search (raw ASCII in HBM, one encode launch, ONE search launch); search_only = the sequences "
-                      "already set (another offset range, another mode); from_host_buffers = psa_set_sequences + psa_search"}
+              "one_shot_retries": ctx.raw_retry_count(),
+              "note": "median wall time of blocking calls, device idle before each: latency = psa_search_device (raw ASCII in "
+                      "HBM -> result, ONE launch: the count kernel reads the ASCII itself); encode_launch_first = "
+                      "psa_set_sequences_device + psa_search (two launches), two_setters = three; search_only = the sequences "
+                      "already set (another offset range, another mode); from_host_buffers = psa_set_sequences + psa_search"})
     one = one_search()
     # ... and through the reference's own entry point gpu_run_program (a ProgramData struct in host memory)
     legacy_us = None

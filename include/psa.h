@@ -145,6 +145,16 @@ psa_status psa_search(psa_context* ctx, int first_offset, int last_offset, psa_r
 psa_status psa_search_async(psa_context* ctx, int first_offset, int last_offset);
 psa_status psa_search_wait(psa_context* ctx, psa_result* out);
 
+/* One-shot search from raw ASCII in device memory — the whole of gpu_run_program's device work as ONE kernel launch
+ * (no encode launch in front: the count kernel reads the ASCII itself, its last workgroup re-scores the survivors and
+ * writes the result).  Blocking.  Replaces the context's sequences (psa_set_seq*): after the call they are unset, or —
+ * when the one launch could not settle the search and the call went through psa_set_sequences_device + psa_search —
+ * set to these.  Same results and errors as that pair of calls. */
+psa_status psa_search_device(psa_context* ctx, const void* d_seq1, int n, const void* d_seq2, int m,
+                             int first_offset, int last_offset, psa_result* out);
+/* one-shot searches redone through the two-launch path (a character outside [A-Z-], > 16 surviving candidates, ...) */
+int psa_raw_retry_count(psa_context* ctx);
+
 /* Batch of nq queries (BASELINE.json configs[4]): nq Seq2 sequences of m characters
  * each, `stride` bytes apart in one buffer (host memory for psa_search_batch, device
  * memory for psa_search_batch_device), all searched over offsets [first,last) of the

@@ -390,6 +390,7 @@ struct psa_context {
     int batch_streams = 1;             // count launches of a batch on one stream (2: alternate between two, psa_set_batch_streams)
     int batch_rescore_grid = 8;        // re-score workgroups per query inside a batch (the CUs are busy counting)
     int granted16 = 0;                 // dynamic-LDS grant of the count kernel on this context's device
+    bool granted16_raw = false;
     bool granted_duo = false;
     bool duo = true;                   // batches: one workgroup per tile serves several queries (psa_count_duo_kernel)
     int  duo_queries = 128;            // queries per launch of it (measured: 32 -> 128 per launch -1.1 % per 256-query batch;
@@ -462,6 +463,7 @@ struct psa_context {
     int         fallbacks = 0;               // filter searches redone by the sequential engine
     int         reselects = 0;               // filter searches whose selection ran twice (overflow against the running bound)
     int         unfused = 0;                 // single filter searches finished by psa_rescore_kernel, not inside the count kernel
+    int         raw_retries = 0;             // one-shot searches (psa_search_device) redone through the two-launch path
     int         seq = 0;                     // sequence number of the last search enqueued
     // device groups: the final kernel of a single search also writes its 32-byte record here (device memory)
     psa_result* record_out = nullptr;
@@ -591,16 +593,24 @@ psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
 
 bool plan_filter(int first, int last, int m, FilterPlan* best, int max_chunks = 1 << 30);
 
-// `n` = the Seq1 length the class order is planned for (the context's, or the one being set in the same launch)
-psa_status seq2_args(SearchSlot& s, const void* d_raw, int m, int n, int* d_bad, psa::Seq2Args* a, FilterPlan* p)
+// the slot's three Seq2 buffers hold m symbols (+ the planners' slack)
+psa_status ensure_seq2_capacity(SearchSlot& s, int m)
 {
     const int need = (m + kSeq2Slack + 63) & ~63;
     if (need > s.m_cap) {
+        s.m_cap = 0;
         PSA_TRY(dev_alloc(&s.d_s2rows, (size_t)need));
         PSA_TRY(dev_alloc(&s.d_s2bytes, (size_t)need));
         PSA_TRY(dev_alloc(&s.d_s2cls, (size_t)need));
         s.m_cap = need;
     }
+    return PSA_OK;
+}
+
+// `n` = the Seq1 length the class order is planned for (the context's, or the one being set in the same launch)
+psa_status seq2_args(SearchSlot& s, const void* d_raw, int m, int n, int* d_bad, psa::Seq2Args* a, FilterPlan* p)
+{
+    PSA_TRY(ensure_seq2_capacity(s, m));
     s.m = -1;
     // class order for the chunking a search over every offset will use (a search of another range
     // that plans differently re-orders them: ensure_class_order)
@@ -947,6 +957,8 @@ psa::RescoreArgs rescore_args(const psa_context* c, const SearchSlot& s, long lo
     r.s2_stride = 0;
     r.record_out = nullptr;
     r.record_shard = -1;
+    r.raw = 0;
+    r.n1 = c->n;
     return r;
 }
 
@@ -955,9 +967,18 @@ psa::RescoreArgs rescore_args(const psa_context* c, const SearchSlot& s, long lo
 // `s2`/`ts2` (optional): a second search of the same Seq2 in another mode, selected in the same pass.
 // `fused`: a single search that ends inside this launch (the last tile workgroup re-scores the candidates and writes
 // the tail); otherwise psa_rescore_kernel follows.
+struct RawSequences {                 // a one-shot search's inputs: the caller's ASCII in device memory
+    const unsigned char* seq1;
+    int                  n;
+    const unsigned char* seq2;
+    int                  m;
+};
+
+// `raw`: the launch reads the caller's ASCII itself (psa_count_kernel<16, true>: no encode launch in front of it).
 psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int base, int span_pad, int first,
                         int span, bool inline_select, hipStream_t stream, const TableSet& ts,
-                        const SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr, bool fused = false)
+                        const SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr, bool fused = false,
+                        const RawSequences* raw = nullptr)
 {
     if (p.nchunks > 1 && inline_select && !s.d_arrivals) { set_last_error("internal: no arrival counters"); return PSA_ERR_STATE; }
     psa::CountArgs a;
@@ -994,7 +1015,33 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.tail = rescore_args(c, s, (long long)span * s.m, ts);
     a.tail.record_out = c->record_out;
     a.tail.record_shard = c->record_shard;
+    a.raw1 = a.raw2 = nullptr;
+    a.classes_w = nullptr;
+    a.bad = c->d_bad;
+    a.n1 = a.m2 = a.class_total = 0;
     const dim3 grid(p.ntiles, p.nchunks);
+    if (raw) {
+        if (!fused || s2 || s.s2cls != s.d_s2cls) { set_last_error("internal: a raw launch is a fused single search"); return PSA_ERR_STATE; }
+        a.raw1 = raw->seq1;
+        a.n1 = raw->n;
+        a.raw2 = raw->seq2;
+        a.m2 = raw->m;
+        a.classes_w = s.d_s2cls;
+        a.class_total = p.nchunks * psa::kClasses * p.class_chars;
+        a.tail.raw = 1;
+        a.tail.n1 = raw->n;
+        a.tail.s1 = raw->seq1;
+        a.tail.s2 = raw->seq2;
+        if (!c->granted16_raw) {
+            PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16, true>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, psa::kCountLdsBytes));   // (+ 2.3 KB static)
+            c->granted16_raw = true;
+        }
+        hipLaunchKernelGGL((psa::psa_count_kernel<16, true>), grid, dim3(16 * 64), p.lds_bytes, stream, a);
+        c->last_kernel = "psa_count_kernel<16, raw>";
+        PSA_HIP(hipGetLastError());
+        return PSA_OK;
+    }
     // dynamic LDS above 64 KB has to be granted per kernel (and device: the flags live in the context)
     if (p.lds_bytes > c->granted16) {
         PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16>),
@@ -1117,7 +1164,7 @@ psa_status plan_on_slot(SearchSlot& s, int first, int last, hipStream_t stream, 
 // count + bounds + candidate selection: one kernel (chunk workgroups of a tile combine in the kernel)
 psa_status launch_filter_front(psa_context* c, SearchSlot& s, const FilterPlan& p, int first, int last, hipStream_t stream,
                                bool profile, const TableSet& ts, SearchSlot* s2 = nullptr, const TableSet* ts2 = nullptr,
-                               bool fused = false)
+                               bool fused = false, const RawSequences* raw = nullptr)
 {
     const int span = last - first;
     const int base = first & ~31;
@@ -1125,7 +1172,7 @@ psa_status launch_filter_front(psa_context* c, SearchSlot& s, const FilterPlan& 
     s.inline_select = true;
     if (s2) s2->inline_select = true;
     if (profile) PSA_HIP(hipEventRecord(c->ev[2], stream));
-    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, true, stream, ts, s2, ts2, fused));
+    PSA_TRY(launch_count(c, s, p, base, span_pad, first, span, true, stream, ts, s2, ts2, fused, raw));
     if (profile) PSA_HIP(hipEventRecord(c->ev[3], stream));
     return PSA_OK;
 }
@@ -1591,6 +1638,72 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
     return PSA_OK;
 }
 
+// One-shot search from raw ASCII in device memory: ONE launch, no encode launch in front of it — the count kernel
+// converts Seq1's windows while it builds its planes, every workgroup writes Seq2's class-ordered symbols itself, and
+// the search's last workgroup re-scores the survivors from the ASCII.  Anything the one launch does not settle (a
+// character outside [A-Z-], candidate-list overflow, more than 16 survivors, the sequential engine being the better
+// one for the shape) goes through psa_set_sequences_device + psa_search.  The context's own sequences are replaced
+// (forgotten after a one-launch search, set after a fallback).
+psa_status psa_search_device(psa_context* c, const void* d_seq1, int n, const void* d_seq2, int m,
+                             int first, int last, psa_result* out)
+{
+    if (!c || !d_seq1 || !d_seq2 || !out || n < 1 || m < 1) { set_last_error("psa_search_device: bad arguments"); return PSA_ERR_ARG; }
+    if (!c->have_weights) { set_last_error("weights must be set before a search"); return PSA_ERR_STATE; }
+    if (c->pending) { set_last_error("psa_search_device: a psa_search_async is still in flight"); return PSA_ERR_STATE; }
+    const long long total = (long long)n - m + 1;
+    if (total < 1) { set_last_error("need 1 <= len(seq2) <= len(seq1)"); return PSA_ERR_ARG; }
+    if (first < 0 || last > total || first >= last) {
+        set_last_error("offset range must satisfy 0 <= first < last <= len(seq1)-len(seq2)+1");
+        return PSA_ERR_ARG;
+    }
+    DeviceScope device_scope;
+    PSA_TRY(ensure_device(c));
+    SearchSlot& s = c->slot[0];
+    auto two_launches = [&]() -> psa_status {
+        PSA_TRY(encode_pair(c, d_seq1, n, d_seq2, m));
+        return psa_search(c, first, last, out);
+    };
+    FilterPlan plan;
+    if (c->profiling || !use_filter(c, first, last, m) || !plan_filter(first, last, m, &plan) ||
+        psa::fused_candidates_at_a_time(plan.lds_bytes, m) < 1)
+        return two_launches();
+    PSA_TRY(ensure_seq2_capacity(s, m));
+    c->n = -1;                                     // what the context held is gone either way
+    s.m = m;
+    s.s2rows = s.d_s2rows;
+    s.s2bytes = s.d_s2bytes;
+    s.s2cls = s.d_s2cls;
+    s.cls_chars = plan.class_chars;                // (the launch writes the class order itself)
+    s.cls_chunks = plan.nchunks;
+    if (plan.nchunks > 1) PSA_TRY(ensure_chunk_scratch(&s.d_partial, &s.partial_cap, &s.d_arrivals, &s.arrivals_cap, plan, c->stream));
+    c->timing_valid = false;
+    c->seq += 1;
+    s.d_tail = c->hd_tails;
+    c->record_out = nullptr;
+    c->record_shard = -1;
+    c->last_kernel_queries = 1;
+    if (s.scal_dirty) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
+    s.scal_dirty = true;
+    const RawSequences raw = {static_cast<const unsigned char*>(d_seq1), n, static_cast<const unsigned char*>(d_seq2), m};
+    const psa_status launched = launch_filter_front(c, s, plan, first, last, c->stream, false, primary_tables(c), nullptr, nullptr,
+                                                    true, &raw);
+    s.m = -1;                                      // the slot holds no encoded Seq2
+    PSA_TRY(launched);
+    if (!tail_arrived(c, 400.0)) PSA_HIP(hipStreamSynchronize(c->stream));
+    const psa::SearchTail& t = c->h_tails[0];
+    if (t.seq == c->seq && t.overflow == 0 && t.bad == 0) {
+        s.scal_dirty = false;                      // the search ran to its end: its last workgroup zeroed the scalars
+        *out = t.result;
+        return PSA_OK;
+    }
+    // not settled by the one launch: the two-launch path decides (and reports alphabet errors)
+    PSA_HIP(hipStreamSynchronize(c->stream));
+    PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
+    *c->h_bad = 0;
+    c->raw_retries += 1;
+    return two_launches();
+}
+
 psa_status psa_search(psa_context* c, int first, int last, psa_result* out)
 {
     PSA_TRY(psa_search_async(c, first, last));
@@ -2033,6 +2146,9 @@ int psa_reselect_count(psa_context* c) { return c ? c->reselects : 0; }
 // Single filter searches of this context that psa_rescore_kernel finished (a second launch): more surviving candidates
 // than the count kernel's last workgroup re-scores itself (16), or a Seq2 whose class codes do not fit its LDS.
 int psa_unfused_count(psa_context* c) { return c ? c->unfused : 0; }
+
+// One-shot searches (psa_search_device) that the one launch did not settle and the two-launch path redid.
+int psa_raw_retry_count(psa_context* c) { return c ? c->raw_retries : 0; }
 
 // Batches this context ran a second time without the batch count kernel because one of its wave-group
 // barriers timed out (never expected; the debug library can force it: PSA_DUO_FORCE_TIMEOUT).
@@ -2497,12 +2613,12 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
         psa_context* c = g_legacy_ctx;
         if (psa_set_weights(c, weights, is_max) != PSA_OK) legacy_die("Failed to build the score tables");
         // The two arrays of a ProgramData lie side by side: one copy command (the reference copies the whole struct,
-        // cuda_funcs.cu:50), one encode launch, one search launch, and the call synchronises once, at the end of the
-        // search: the alphabet flag comes back with the result tail.
-        if (n < 1 || ensure_device(c) != PSA_OK || stage_host_pair(c, seq1, (size_t)n, seq2, (size_t)m) != PSA_OK ||
-            encode_pair(c, c->d_raw, n, c->d_raw + c->raw_second, m) != PSA_OK)
+        // cuda_funcs.cu:50) and ONE launch that reads the ASCII itself; the alphabet flag comes back with the result
+        // tail.
+        if (n < 1 || ensure_device(c) != PSA_OK || stage_host_pair(c, seq1, (size_t)n, seq2, (size_t)m) != PSA_OK)
             legacy_die("Failed to copy data from host to device");
-        if (psa_search(c, first_offset, last_offset, &r) != PSA_OK) legacy_die("Failed to run the search");
+        if (psa_search_device(c, c->d_raw, n, c->d_raw + c->raw_second, m, first_offset, last_offset, &r) != PSA_OK)
+            legacy_die("Failed to run the search");
     }
     if (r.offset < 0 || r.ch == 0) return none;   // cuda_funcs.cu:143-144
     returned_mutant->offset = r.offset;

@@ -574,6 +574,32 @@ __device__ __forceinline__ double thread_bounds(const BoundParams& b, const unsi
     return pess;
 }
 
+// ---- values other workgroups wrote / will read inside the same launch ----------------
+// Write-through (sc1) stores and agent-scope loads: they pass the XCD's L2, so the hand-off needs no L2 write-back
+// (MI355X_MICROARCH.md, "Valid forms": every storing wave drains its stores, workgroup barrier, ONE lane's arrival).
+__device__ __forceinline__ void store_agent(int* p, int v)
+{
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void store_agent(double* p, double v)
+{
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int load_agent(const int* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long load_agent(const unsigned long long* p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_agent(const double* p)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
 // ---- rescore: the reference's sequential fp64 sum for each candidate -----------
 // One wave per candidate.  The additions of cpu_funcs.c:278 are a serial chain of
 // m roundings, but while the running sum stays inside one binade every addend is
@@ -615,6 +641,8 @@ struct RescoreArgs {
     int is_max;
     int fast_ok;                    // all weights normal doubles or zero
     int fast_min_exp;               // smallest biased exponent of the running sum the walk handles
+    int raw;                        // 1 (one-shot searches): s1 / s2 are the caller's raw ASCII (n1 / m bytes), not codes
+    int n1;
     int certify;                    // 1: try the certified segment sum first (certified_sum), the walk is its fallback
     double walk_slack;              // rigorous bound of |sequential fp64 prefix sum - order-free prefix sum| over the m chars
     // blockIdx.y = query of a batch launch: its state lies query_stride... further on (all 0 for one search)
@@ -668,17 +696,47 @@ __device__ __forceinline__ long long readlane64(long long v, int l)
 // offset) into LDS, chunk-relative, four chars per thread and step; positions from c1 up to the walk's
 // over-read are padding (class 4, addend +0.0).  `key` collects max(rank << 32 | ~i): best delta rank, then
 // the lowest char index (cpu_funcs.c:287-294: strict compare keeps the first i).
+// ASCII -> symbol code (psa_internal.hpp): 'A'..'Z' -> 0..25, '-' -> 26, anything else -> the padding symbol
+__device__ __forceinline__ unsigned ascii_code(unsigned c)
+{
+    return c - 'A' < 26u ? c - 'A' : (c == (unsigned)'-' ? (unsigned)kCodeHyphen : (unsigned)kCodePad);
+}
+
+// Four consecutive symbols of a sequence as codes, one per byte.  Encoded sequences (RAW = false) are padded with the
+// padding symbol far beyond their end; raw ASCII (a caller's buffer of `limit` bytes) is not read behind its end.
+template <bool RAW>
+__device__ __forceinline__ unsigned load_codes4(const unsigned char* __restrict__ seq, int i, int limit)
+{
+    unsigned w;
+    if constexpr (!RAW) {
+        (void)limit;
+        __builtin_memcpy(&w, seq + i, 4);
+        return w;
+    } else {
+        if (i + 4 <= limit) __builtin_memcpy(&w, seq + i, 4);
+        else {
+            w = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w |= (i + j < limit ? (unsigned)seq[i + j] : 0u) << (8 * j);
+        }
+        unsigned codes = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) codes |= ascii_code((w >> (8 * j)) & 0xffu) << (8 * j);
+        return codes;
+    }
+}
+
+template <bool RAW = false>
 __device__ __forceinline__ void classify_chars(const unsigned char* __restrict__ s1, const unsigned char* __restrict__ s2,
                                                const unsigned char* s_clsrank, unsigned char* s_codes, int c0, int c1,
-                                               int tid, int nthreads, unsigned long long& key)
+                                               int tid, int nthreads, unsigned long long& key, int limit1 = 0, int limit2 = 0)
 {
     const int groups = (c1 - c0 + 64 * kRescoreEpl + 3) >> 2;
 #pragma unroll 4
     for (int g = tid; g < groups; g += nthreads) {
         const int i = c0 + 4 * g;                         // c0 and the Seq2 code buffer are 4-byte aligned
-        const unsigned w2 = *reinterpret_cast<const unsigned*>(s2 + i);   // both buffers are padded with
-        unsigned w1;                                                         // kCodePad (class 4, rank 0)
-        __builtin_memcpy(&w1, s1 + i, 4);
+        const unsigned w2 = load_codes4<RAW>(s2, i, limit2);             // encoded buffers are padded with
+        const unsigned w1 = load_codes4<RAW>(s1, i, limit1);             // kCodePad (class 4, rank 0)
         unsigned packed = 0u;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1178,33 +1236,7 @@ __device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const Ca
         x.shard = status ? -2 - status : a.record_shard;
         *a.record_out = x;
     }
-    publish_tail(a.out, r, *a.bad, status, a.seq);
-}
-
-// ---- values other workgroups wrote / will read inside the same launch ----------------
-// Write-through (sc1) stores and agent-scope loads: they pass the XCD's L2, so the hand-off needs no L2 write-back
-// (MI355X_MICROARCH.md, "Valid forms": every storing wave drains its stores, workgroup barrier, ONE lane's arrival).
-__device__ __forceinline__ void store_agent(int* p, int v)
-{
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void store_agent(double* p, double v)
-{
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ int load_agent(const int* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned long long load_agent(const unsigned long long* p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double load_agent(const double* p)
-{
-    return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
-                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    publish_tail(a.out, r, load_agent(a.bad), status, a.seq);
 }
 
 #ifdef PSA_PHASE_TIMING
@@ -1236,7 +1268,7 @@ __host__ __device__ inline int fused_candidates_at_a_time(int lds_bytes, int m)
     return g > kFusedWaves ? kFusedWaves : g;
 }
 
-template <int WAVES>
+template <int WAVES, bool RAW>
 __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned char* lds, int lds_bytes, int tid)
 {
     static_assert(WAVES <= kFusedMax, "one walking wave per survivor of a round");
@@ -1314,7 +1346,8 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         const int cnt = nsurv - base < G ? nsurv - base : G;
         for (int j = 0; j < cnt; ++j) {
             unsigned long long key = 0ull;
-            classify_chars(r.s1 + s_surv[base + j], r.s2, s_clsrank, s_codes + (size_t)j * region, 0, m, tid, T, key);
+            classify_chars<RAW>(r.s1 + s_surv[base + j], r.s2, s_clsrank, s_codes + (size_t)j * region, 0, m, tid, T, key,
+                                r.n1 - s_surv[base + j], m);
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) {
                 const unsigned long long other = __shfl_xor(key, d, 64);
@@ -1343,7 +1376,8 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
             }
             const int rank = (int)(key >> 32);
             const int first_i = rank ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffu)) : 0;
-            const unsigned sym2 = r.s2[first_i], sym1 = r.s1[o + first_i];
+            unsigned sym2 = r.s2[first_i], sym1 = r.s1[o + first_i];
+            if constexpr (RAW) { sym2 = ascii_code(sym2); sym1 = ascii_code(sym1); }
             WalkStats st = {0, 0, 0};
             double s = 0.0;
             if (!r.certify ||
@@ -1426,6 +1460,13 @@ struct CountArgs {
     // final bound, surviving candidates, exact re-score, fold, tail).  `tail` = what psa_rescore_kernel would be given.
     int         fused;
     int         lds_bytes;            // dynamic LDS of the launch (the tail carves its buffers out of the dead planes)
+    // psa_count_kernel<16, true> (one-shot searches from raw ASCII, no encode launch in front): the caller's sequences;
+    // every workgroup converts Seq1's window while it builds the planes and writes Seq2's class-ordered symbols itself
+    const unsigned char* raw1;        // n1 bytes
+    const unsigned char* raw2;        // m2 bytes
+    unsigned*   classes_w;            // = classes, writable
+    int*        bad;                  // alphabet flag (bit 0 Seq1, bit 1 Seq2)
+    int         n1, m2, class_total;
     RescoreArgs tail;
 };
 
@@ -1435,7 +1476,7 @@ struct CountArgs {
 #define PSA_PHASE(k) do { } while (0)
 #endif
 
-template <int WAVES>
+template <int WAVES, bool RAW = false>
 __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
 {
     extern __shared__ uint2 lds[];                  // [kMaskRows][lds_slots]; reused by the epilogue
@@ -1456,7 +1497,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     // {'*','.'}, of hi = class in {':','.'}.  A thread fetches the 32 symbol columns of its slot
     // (symbol_planes: bit b = the relation of that Seq1 symbol to b) and transposes the two 32x32
     // bit matrices in registers — 14 KB of codes read per workgroup instead of 100 KB of planes.
-    __shared__ unsigned s_planes[64];
+    // RAW: the table is indexed by the ASCII byte ([2][256]); bit 31 of a lo entry marks a byte outside [A-Z-]
+    __shared__ unsigned s_planes[RAW ? 512 : 64];
     // The tile's count cells have LDS of their own behind the plane rows and start from zero, so a wave adds its counts
     // the moment its main loop ends — the older waves of a SIMD finish 20 us before the youngest, and their
     // transposes and ds_adds run under the others' main loops.
@@ -1471,23 +1513,147 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         const int hi_half = tid >= kHalf ? 1 : 0;
         int slot = tid - kHalf * hi_half;
         const uint4* src = reinterpret_cast<const uint4*>(a.s1 + ((size_t)slot0 << 5));
+        const bool raw_aligned = RAW && (reinterpret_cast<size_t>(a.raw1) & 15) == 0;
+        // the 32 symbols of a slot: codes from the encoded Seq1, or the caller's ASCII (never read behind its end:
+        // positions from n1 on hold byte 0 and are left out of the alphabet check)
+        auto fetch = [&](int sl, uint4& c0, uint4& c1) {
+            if constexpr (!RAW) {
+                c0 = src[2 * sl];
+                c1 = src[2 * sl + 1];
+            } else {
+                const int p0 = (slot0 + sl) << 5;
+                if (raw_aligned && p0 + 32 <= a.n1) {
+                    const uint4* rs = reinterpret_cast<const uint4*>(a.raw1 + p0);
+                    c0 = rs[0];
+                    c1 = rs[1];
+                } else {
+                    unsigned w[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        unsigned v = 0u;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int p = p0 + 4 * q + r;
+                            v |= (p < a.n1 ? (unsigned)a.raw1[p] : 0u) << (8 * r);
+                        }
+                        w[q] = v;
+                    }
+                    c0 = make_uint4(w[0], w[1], w[2], w[3]);
+                    c1 = make_uint4(w[4], w[5], w[6], w[7]);
+                }
+            }
+        };
         uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-        if (slot < a.lds_slots) { c0 = src[2 * slot]; c1 = src[2 * slot + 1]; }
-        if (tid < 64) s_planes[tid] = a.symbol_planes[tid];
+        if (slot < a.lds_slots) fetch(slot, c0, c1);
+        // RAW: this thread's 16 chars of Seq2 (the first of them; asked for together with the Seq1 window)
+        unsigned r2[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
+        const bool raw2_aligned = RAW && (reinterpret_cast<size_t>(a.raw2) & 15) == 0;
+        auto fetch2 = [&](int i0) {
+            if (raw2_aligned && i0 + 16 <= a.m2) {
+                const uint4 q = *reinterpret_cast<const uint4*>(a.raw2 + i0);
+                r2[0] = q.x; r2[1] = q.y; r2[2] = q.z; r2[3] = q.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    unsigned v = 0u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v |= (i0 + 4 * q + r < a.m2 ? (unsigned)a.raw2[i0 + 4 * q + r] : (unsigned)'A') << (8 * r);
+                    r2[q] = v;
+                }
+            }
+        };
+        if constexpr (RAW) {
+            if (tid * 16 < a.m2) fetch2(tid * 16);
+        }
+        if constexpr (!RAW) {
+            if (tid < 64) s_planes[tid] = a.symbol_planes[tid];
+        } else if (tid < 256) {
+            const unsigned code = ascii_code((unsigned)tid);
+            const bool real = code <= (unsigned)kCodeHyphen;
+            s_planes[tid] = (real ? a.symbol_planes[code] : 0u) | (real ? 0u : 0x80000000u);
+            s_planes[256 + tid] = real ? a.symbol_planes[32 + code] : 0u;
+        }
         __syncthreads();
-        const unsigned* tab = s_planes + 32 * hi_half;
+        if constexpr (RAW) {
+            // Seq2's symbols in the count loop's class order (class_index), as psa_encode_seq2_kernel writes them.  Every
+            // workgroup writes ALL of them and reads them back through the scalar cache: what a workgroup reads is its
+            // own store or another workgroup's store of the same value.  The class order is a stride-32 permutation:
+            // the codes are staged in LDS in natural order (in the count cells, which are not needed before the main
+            // loop ends; 4 bytes of padding per 32 codes keep the strided reads off each other's banks) so that the
+            // global stores are coalesced.
+            unsigned char* stage = reinterpret_cast<unsigned char*>(cells);
+            const bool staged = a.m2 + (a.m2 >> 3) + 64 <= kCellDwords * 4;
+            if (staged) {
+                __syncthreads();                                  // (the cells were being zeroed)
+                for (int i0 = tid * 16; i0 < a.m2; i0 += WAVES * 64 * 16) {
+                    if (i0 != tid * 16) fetch2(i0);
+                    bool any_bad = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        unsigned codes = 0u;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const unsigned code = ascii_code((r2[q] >> (8 * r)) & 0xffu);
+                            any_bad |= code == (unsigned)kCodePad;
+                            codes |= code << (8 * r);
+                        }
+                        const int i = i0 + 4 * q;
+                        *reinterpret_cast<unsigned*>(stage + i + 4 * (i >> 5)) = codes;
+                    }
+                    if (any_bad) atomicOr(a.bad, 2);              // a character of Seq2 outside [A-Z-]
+                }
+                __syncthreads();
+            }
+            // position j of the class order holds char i = 32 (c cc + kk) + 31 - cs with j = ((32 c + cs) cc + kk):
+            // one division by cc (a float estimate, corrected)
+            const int total = a.class_total + kUnroll;
+            const int cc = a.class_chars;
+            const float rcc = 1.0f / (float)cc;
+            for (int j = tid; j < total; j += WAVES * 64) {
+                unsigned code = kCodePad;
+                if (j < a.class_total) {
+                    int q = (int)((float)j * rcc);
+                    int kk = j - q * cc;
+                    if (kk < 0) { kk += cc; --q; }
+                    if (kk >= cc) { kk -= cc; ++q; }
+                    const int i = (((q >> 5) * cc + kk) << 5) + (kClasses - 1 - (q & 31));
+                    if (i < a.m2) {
+                        if (staged) code = stage[i + 4 * (i >> 5)];
+                        else {
+                            code = ascii_code(a.raw2[i]);
+                            if (code == (unsigned)kCodePad) atomicOr(a.bad, 2);
+                        }
+                    }
+                }
+                a.classes_w[j] = code << kRowShift;
+            }
+            if (staged) {
+                __syncthreads();                                  // every staged code has been read: the cells again
+                for (int i = tid; i < kCellDwords; i += WAVES * 64) cells[i] = 0u;
+            }
+        }
+        const unsigned* tab = s_planes + (RAW ? 256 : 32) * hi_half;
         unsigned* dst = reinterpret_cast<unsigned*>(lds) + hi_half;
+        unsigned seen = 0u;
         while (slot < a.lds_slots) {
             const unsigned w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
             const int next = slot + kHalf;
-            if (next < a.lds_slots) { c0 = src[2 * next]; c1 = src[2 * next + 1]; }
+            if (next < a.lds_slots) fetch(next, c0, c1);
             unsigned v[32];
+            const int in_range = RAW ? a.n1 - ((slot0 + slot) << 5) : 32;        // chars of this slot inside Seq1
 #pragma unroll
-            for (int t = 0; t < 32; ++t) v[t] = tab[(w[t >> 2] >> (8 * (t & 3))) & 0xffu];
+            for (int t = 0; t < 32; ++t) {
+                v[t] = tab[(w[t >> 2] >> (8 * (t & 3))) & 0xffu];
+                if constexpr (RAW) seen |= t < in_range ? v[t] : 0u;
+            }
             transpose32(v);
 #pragma unroll
             for (int b = 0; b < kMaskRows; ++b) dst[(b * row_slots + slot) * 2] = v[b];
             slot = next;
+        }
+        if constexpr (RAW) {
+            if (seen >> 31) atomicOr(a.bad, 1);             // a character of Seq1 outside [A-Z-]
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's symbol stores have reached the L2
         }
     }
     __syncthreads();
@@ -1509,6 +1675,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     const int class_chars = __builtin_amdgcn_readfirstlane(a.class_chars);    // (loaded under a divergent branch above)
     const int sym_at = __builtin_amdgcn_readfirstlane(((int)blockIdx.y * kClasses + (kClasses - kWaveClasses - low_class)) * class_chars);
     const_u32* sym = (const_u32*)(size_t)(a.classes + sym_at);
+    if constexpr (RAW) {
+        // the symbols were stored in this launch (behind the barrier above): drop what the scalar cache holds, and tie
+        // the pointer to that point so that no scalar load of the symbols can be scheduled in front of it
+        asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(sym) : : "memory");
+    }
     const unsigned lane_base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds + (unsigned)lane * 8u;
     count_classes(cnt, sym, kWaveClasses, class_chars, (unsigned)low_class, lane_base, lane, row_of);
 
@@ -1620,7 +1791,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     }
     __syncthreads();
     if (!s_last_tile) return;
-    finish_search<WAVES>(a.tail, reinterpret_cast<unsigned char*>(lds), a.lds_bytes, tid);
+    finish_search<WAVES, RAW>(a.tail, reinterpret_cast<unsigned char*>(lds), a.lds_bytes, tid);
     PSA_PHASE(7);
 }
 

@@ -33,7 +33,8 @@ EXPORTED_SYMBOLS = (
     "psa_create", "psa_destroy", "psa_set_weights",
     "psa_set_seq1", "psa_set_seq2", "psa_set_seq1_device", "psa_set_seq2_device",
     "psa_set_sequences", "psa_set_sequences_device",
-    "psa_set_engine", "psa_set_batch_streams", "psa_search", "psa_search_async", "psa_search_wait", "psa_scores",
+    "psa_set_engine", "psa_set_batch_streams", "psa_search", "psa_search_async", "psa_search_wait", "psa_search_device",
+    "psa_raw_retry_count", "psa_scores",
     "psa_search_batch", "psa_search_batch_device",
     "psa_search_batch_minmax", "psa_search_batch_minmax_device",
     "psa_debug_counts", "psa_fallback_count", "psa_reselect_count", "psa_unfused_count", "psa_duo_retry_count", "psa_debug_rescore",
@@ -89,6 +90,8 @@ def _load() -> C.CDLL:
     lib.psa_set_batch_streams.argtypes = [vp, i]
     lib.psa_search.argtypes = [vp, i, i, C.POINTER(Result)]
     lib.psa_search_async.argtypes = [vp, i, i]
+    lib.psa_search_device.argtypes = [vp, vp, i, vp, i, i, i, C.POINTER(Result)]
+    lib.psa_raw_retry_count.argtypes = [vp]
     lib.psa_search_wait.argtypes = [vp, C.POINTER(Result)]
     lib.psa_scores.argtypes = [vp, i, i, vp, vp, vp]
     lib.psa_search_batch.argtypes = [vp, C.c_char_p, i, i, C.c_size_t, i, i, C.POINTER(Result)]
@@ -284,6 +287,19 @@ class Context:
         out = Result()
         _check(lib.psa_search(self._h, first, last, C.byref(out)))
         return out
+
+    def search_device(self, ptr1: int, n: int, ptr2: int, m: int, first: Optional[int] = None, last: Optional[int] = None) -> Result:
+        """One-shot search from raw ASCII in device memory: one kernel launch (psa_search_device)."""
+        first = 0 if first is None else first
+        last = n - m + 1 if last is None else last
+        out = Result()
+        _check(lib.psa_search_device(self._h, C.c_void_p(ptr1), n, C.c_void_p(ptr2), m, first, last, C.byref(out)))
+        self.n = self.m = None
+        return out
+
+    def raw_retry_count(self) -> int:
+        """One-shot searches the one launch did not settle (redone through set_sequences_device + search)."""
+        return lib.psa_raw_retry_count(self._h)
 
     def search_async(self, first: int, last: int):
         _check(lib.psa_search_async(self._h, first, last))

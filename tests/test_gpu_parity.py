@@ -557,6 +557,90 @@ def test_single_search_is_one_launch_unless_too_many_survive(psa, oracle, refere
         assert c.unfused_count() == before and c.fallback_count() == 0 and c.reselect_count() == 0
 
 
+def test_one_shot_search_from_raw_ascii(psa, oracle, reference_records):
+    """psa_search_device: raw ASCII in device memory -> result in ONE launch (the count kernel reads the ASCII itself:
+    Seq1 while it builds its planes, Seq2's class-ordered symbols written by every workgroup, the tail re-scoring from
+    the ASCII) == psa_set_sequences_device + psa_search == the oracle, for tile-boundary and odd lengths, sub-ranges,
+    unaligned buffers, hyphens, multi-chunk plans, the shapes that go to the sequential engine, records whose ties
+    need the second launch (two-launch path behind the scenes), and a bad character in either sequence."""
+    import torch
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch, r.pairs)
+    rng = np.random.default_rng(77)
+    alpha = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY-", np.uint8)
+
+    def dev(b, shift=0):
+        t = torch.zeros(len(b) + shift + 64, dtype=torch.uint8)
+        t[shift:shift + len(b)] = torch.frombuffer(bytearray(b), dtype=torch.uint8)
+        t[shift + len(b):] = ord("a")                     # anything read behind the end would be a bad character
+        return t.cuda()
+
+    with psa.Context(0) as c, psa.Context(0) as ref:
+        cases = [(reference_records[k][1], reference_records[k][2], reference_records[k][0], reference_records[k][3])
+                 for k in (0, 5, 9, 11, 13)]
+        cases += [(psa.generate_sequence(81, 300_000), psa.generate_sequence(82, 3000), W_README, True),
+                  (psa.generate_sequence(83, 131_071), psa.generate_sequence(84, 4097), W_README, False),
+                  (psa.generate_sequence(85, 65_000), psa.generate_sequence(86, 13_000), [1, 3, 4, 2], True),     # char chunks
+                  (psa.generate_sequence(87, 50_000), psa.generate_sequence(88, 20_001), W_README, False),
+                  (rng.choice(alpha, 40_003).tobytes(), rng.choice(alpha, 901).tobytes(), [0.8, 0.54, 2.6, 13.7], True),
+                  (psa.generate_sequence(89, 5000), psa.generate_sequence(90, 33), W_README, True)]           # sequential engine
+        for s1, s2, w, is_max in cases:
+            n, m = len(s1), len(s2)
+            total = n - m + 1
+            for shift in (0, 3):
+                t1, t2 = dev(s1, shift), dev(s2, shift)
+                torch.cuda.synchronize()
+                for sub in ((0, total), (total // 3, total - total // 5)):
+                    if sub[1] <= sub[0]:
+                        continue
+                    c.set_weights(w, is_max)
+                    got = c.search_device(t1.data_ptr() + shift, n, t2.data_ptr() + shift, m, *sub)
+                    ref.set_weights(w, is_max)
+                    ref.set_sequences_device(t1.data_ptr() + shift, n, t2.data_ptr() + shift, m)
+                    assert key(got) == key(ref.search(*sub)), (n, m, shift, sub)
+            if n * m <= 40_000_000:
+                assert_same(c.search_device(t1.data_ptr() + 3, n, t2.data_ptr() + 3, m), oracle.search(s1, s2, w, is_max, threads=8))
+        assert c.raw_retry_count() >= 2                      # records 9 and 13: more than 16 exact ties
+        # the context's own sequences are gone after a one-launch search (the last case went the two-launch way)
+        s1, s2 = cases[5][0], cases[5][1]
+        t1, t2 = dev(s1), dev(s2)
+        torch.cuda.synchronize()
+        before = c.raw_retry_count()
+        c.search_device(t1.data_ptr(), len(s1), t2.data_ptr(), len(s2))
+        assert c.raw_retry_count() == before
+        with pytest.raises(psa.PsaError) as e:
+            c.search(0, 1)
+        assert e.value.status == psa.PSA_ERR_STATE
+        # a character outside [A-Z-] in either sequence
+        s1, s2 = psa.generate_sequence(91, 70_000), psa.generate_sequence(92, 1500)
+        for bad1, bad2 in ((69_999, None), (17, None), (None, 0), (None, 1499)):
+            b1 = bytearray(s1)
+            b2 = bytearray(s2)
+            if bad1 is not None:
+                b1[bad1] = ord("z")
+            if bad2 is not None:
+                b2[bad2] = 1
+            t1, t2 = dev(bytes(b1)), dev(bytes(b2))
+            torch.cuda.synchronize()
+            with pytest.raises(psa.PsaError) as e:
+                c.search_device(t1.data_ptr(), len(s1), t2.data_ptr(), len(s2))
+            assert e.value.status == psa.PSA_ERR_ALPHABET
+        t1, t2 = dev(s1), dev(s2)
+        torch.cuda.synchronize()
+        c.set_weights(W_README, True)
+        assert_same(c.search_device(t1.data_ptr(), len(s1), t2.data_ptr(), len(s2)), oracle.search(s1, s2, W_README, True, threads=8))
+        # full size against the committed goldens
+        gold = {g["name"]: g for g in json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))["cases"]}
+        t1, t2 = dev(psa.generate_sequence(1002, 1_000_000)), dev(psa.generate_sequence(2002, 10_000))
+        torch.cuda.synchronize()
+        before = c.raw_retry_count()
+        for is_max, name in ((True, "c3_max"), (False, "c3_min")):
+            c.set_weights(W_README, is_max)
+            r = c.search_device(t1.data_ptr(), 1_000_000, t2.data_ptr(), 10_000)
+            g = gold[name]
+            assert (r.offset, r.char_offset, chr(r.ch), "%.17g" % r.score) == (g["offset"], g["char_offset"], g["ch"], g["score"])
+        assert c.raw_retry_count() == before and c.fallback_count() == 0
+
+
 def test_set_sequences_equals_the_two_setters(psa):
     """psa_set_sequences / psa_set_sequences_device (one encode launch for both sequences) == psa_set_seq1 + psa_set_seq2,
     for adjacent host buffers (one copy command), separate ones, device buffers, and a bad character in either."""

@@ -70,10 +70,16 @@ def legacy():
     return psa.lib.gpu_run_program_layout(C.addressof(data), cap1, cap2, C.byref(mutant), 0, n - m + 1)
 
 
+def one_shot():
+    return ctx.search_device(t1.data_ptr(), n, t2.data_ptr(), m)
+
+
 r = two_encodes()
 print(f"result {r.offset} {r.score!r}  unfused {ctx.unfused_count()}")
 print(f"HBM inputs, set_seq1_device + set_seq2_device + search : {med(two_encodes):7.1f} us")
 print(f"HBM inputs, set_sequences_device + search              : {med(one_encode):7.1f} us")
+print(f"HBM inputs, psa_search_device (ONE launch)             : {med(one_shot):7.1f} us   (retries {ctx.raw_retry_count()})")
+ctx.set_sequences_device(t1.data_ptr(), n, t2.data_ptr(), m)
 print(f"sequences already set, search only                     : {med(ctx.search):7.1f} us")
 print(f"host inputs, set_seq1 + set_seq2 + search              : {med(host_two):7.1f} us")
 print(f"host inputs, set_sequences + search                    : {med(host_pair):7.1f} us")

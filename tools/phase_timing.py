@@ -8,6 +8,7 @@ import os
 import sys
 
 import numpy as np
+import torch  # noqa: F401  (its HIP runtime first, see tests/conftest.py)
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "parallel-sequence-alignment_amd"))
 import psa_amd  # noqa: E402
@@ -16,12 +17,20 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 m = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 last = int(sys.argv[4]) if len(sys.argv) > 4 else n - m + 1
+raw = os.environ.get("PHASE_RAW") == "1"          # the one-shot search from raw ASCII (psa_count_kernel<16, raw>)
 ctx = psa_amd.Context()
 ctx.set_weights([1.5, 2.6, 0.3, 0.2], True)
 ctx.set_seq1(psa_amd.generate_sequence(1002, n))
 ctx.set_seq2(psa_amd.generate_sequence(2002, m))
+if raw:
+    d1 = torch.from_numpy(psa_amd.generate_sequence_np(1002, n)).cuda()
+    d2 = torch.from_numpy(psa_amd.generate_sequence_np(2002, m)).cuda()
+    torch.cuda.synchronize()
 for _ in range(3):
-    r = ctx.search(first, last)
+    r = ctx.search_device(d1.data_ptr(), n, d2.data_ptr(), m, first, last) if raw else ctx.search(first, last)
+if raw:
+    ctx.set_seq1(psa_amd.generate_sequence(1002, n))
+    ctx.set_seq2(psa_amd.generate_sequence(2002, m))
 lib = psa_amd._lib if hasattr(psa_amd, "_lib") else psa_amd.lib
 buf = (C.c_ulonglong * (1024 * 8))()
 lib.psa_debug_phase_ts.restype = C.c_int

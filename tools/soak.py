@@ -47,6 +47,12 @@ with psa.Context(0) as cf, psa.Context(0) as cs, psa.Context(0) as ca:      # ca
         assert key(single) == key(one[-1]), ("single vs batch", n, m, nq, w, first, last)
         ca.set_sequences(s1, qs[-1])                        # both sequences by one encode launch
         assert key(ca.search(first, last)) == key(single), ("auto engine", n, m, nq, w, first, last)
+        d1 = torch.frombuffer(bytearray(s1), dtype=torch.uint8).cuda()
+        d2 = torch.frombuffer(bytearray(qs[-1]), dtype=torch.uint8).cuda()
+        torch.cuda.synchronize()
+        for c in (cf, ca):                                  # one-shot search from raw ASCII: one launch
+            assert key(c.search_device(d1.data_ptr(), n, d2.data_ptr(), m, first, last)) == key(single), ("one-shot", n, m, w, first, last)
+            c.set_seq1(s1)
         assert [key(r) for r in one] == [key(r) for r in hi], ("batch vs minmax", n, m, nq, w, first, last)
         for mode, got in ((True, hi), (False, lo)):
             cs.set_weights(w, mode)
@@ -59,5 +65,6 @@ with psa.Context(0) as cf, psa.Context(0) as cs, psa.Context(0) as ca:      # ca
             t_note = time.time() + 60.0
     print(f"soak: {cases} random cases ok; filter context: {cf.fallback_count()} sequential-engine fallbacks (ties), "
           f"{cf.reselect_count()} reselects, {cf.unfused_count()} second launches (> 16 survivors or a long Seq2), "
-          f"{cf.duo_retry_count()} retried batches (a group barrier gave up: expected 0)")
+          f"{cf.duo_retry_count()} retried batches (a group barrier gave up: expected 0), "
+          f"{cf.raw_retry_count()} one-shot searches redone through the two-launch path")
     assert cf.duo_retry_count() == 0 and ca.duo_retry_count() == 0
