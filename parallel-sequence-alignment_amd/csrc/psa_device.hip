@@ -391,6 +391,17 @@ struct psa_context {
     int batch_rescore_grid = 8;        // re-score workgroups per query inside a batch (the CUs are busy counting)
     int granted16 = 0;                 // dynamic-LDS grant of the count kernel on this context's device
     bool granted16_raw = false;
+    // Shares of a SIMD's four waves in the single-search count kernel, by age (oldest first), in permille.  The hardware
+    // issues the oldest wave of a SIMD first: with equal shares it finished 25 us before the youngest and the SIMD ended on
+    // one wave that cannot fill its issue slots.  Measured, 1M x 10k, kernel us (whole classes): 2/2/2/2 87.8, 3/2/2/1
+    // 81.3, 2/3/2/1 84.5, 3/3/1/1 86.4, 3/3/2/0 86.0, 1/2/2/3 99.0; in rounds of 32 chars around 3/2/2/1 (same box):
+    // 375/250/250/125 89.3, 340/270/250/140 87.6, 330/280/240/150 87.8, 350/260/240/150 88.0, 400/250/225/125 91.6
+    int  single_deal[4] = {340, 270, 250, 140};
+    // Batch kernel: share of a group's four older waves (the younger ones take the rest).  Its waves run with the younger
+    // ones at the higher priority, so THEY finish first: measured per 256-query step 500 -> 15.27 ms, 375 -> 14.08 ms,
+    // 250 -> 16.3 ms, 625 -> slower still; per 32-query launch 375 2.006 ms, 350 2.04, 400 2.07, 325 2.09, 425 2.10, 450 2.11
+    // (shares that split a class pay a counter shift and a restart more)
+    int  duo_older_permille = 375;
     bool granted_duo = false;
     bool duo = true;                   // batches: one workgroup per tile serves several queries (psa_count_duo_kernel)
     int  duo_queries = 128;            // queries per launch of it (measured: 32 -> 128 per launch -1.1 % per 256-query batch;
@@ -967,6 +978,62 @@ psa::RescoreArgs rescore_args(const psa_context* c, const SearchSlot& s, long lo
 // `s2`/`ts2` (optional): a second search of the same Seq2 in another mode, selected in the same pass.
 // `fused`: a single search that ends inside this launch (the last tile workgroup re-scores the candidates and writes
 // the tail); otherwise psa_rescore_kernel follows.
+// ---- who counts what: the waves' shares of a workgroup's symbol stream ------------------------------------------
+// The stream of a chunk is 32 classes x R rounds (R = class_chars / 32); the four waves that share a SIMD (ages 0..3:
+// waves s, s+4, s+8, s+12 of the workgroup) count 8 R rounds between them.  The hardware does not treat them alike —
+// it issues the oldest wave of a SIMD first — so equal shares leave the SIMD on one wave that cannot fill its issue
+// slots for the last third of the loop.  `permille[g]` = the share of age g; every share is capped by what a wave's
+// counters hold (`cap` rounds), the rest goes to the other ages.
+void deal_rounds(int rounds_per_class, const int permille[4], int cap, int q[4])
+{
+    const int total = 8 * rounds_per_class;
+    int left = total;
+    for (int g = 0; g < 4; ++g) {
+        q[g] = std::min(cap, (total * permille[g] + 500) / 1000);
+        left -= q[g];
+    }
+    for (int pass = 0; pass < 64 && left != 0; ++pass)          // rounding and caps: hand the difference round by round
+        for (int g = 3; g >= 0 && left != 0; --g) {
+            if (left > 0 && q[g] < cap) { ++q[g]; --left; }
+            else if (left < 0 && q[g] > 0) { --q[g]; ++left; }
+        }
+}
+
+// psa_count_kernel<16>: wave w has age w / 4 and SIMD w % 4; the ages' shares lie one after the other in the stream
+bool deal_single(const psa_context* c, int class_chars, unsigned short lo[16], unsigned short hi[16])
+{
+    const int R = class_chars / psa::kUnroll;
+    int q[4];
+    deal_rounds(R, c->single_deal, psa::kMaxWaveChars / psa::kUnroll, q);
+    if (q[0] + q[1] + q[2] + q[3] != 8 * R) return false;
+    int at = 0;
+    for (int g = 0; g < 4; ++g)
+        for (int s = 0; s < 4; ++s) {
+            lo[4 * g + s] = (unsigned short)at;
+            at += q[g];
+            hi[4 * g + s] = (unsigned short)at;
+        }
+    return at == psa::kClasses * R;
+}
+
+// psa_count_duo_kernel: a group's waves 0..3 are the older ones of their SIMDs, 4..7 the younger ones
+bool deal_duo(const psa_context* c, int class_chars, unsigned short lo[8], unsigned short hi[8])
+{
+    const int R = class_chars / psa::kUnroll;
+    const int cap = psa::kDuoMaxWaveChars / psa::kUnroll;
+    int older = std::min(cap, (8 * R * c->duo_older_permille + 500) / 1000);
+    int younger = 8 * R - older;
+    if (younger > cap) { younger = cap; older = 8 * R - younger; }
+    if (older > cap || older < 0) return false;
+    int at = 0;
+    for (int w = 0; w < 8; ++w) {
+        lo[w] = (unsigned short)at;
+        at += w < 4 ? older : younger;
+        hi[w] = (unsigned short)at;
+    }
+    return at == psa::kClasses * R;
+}
+
 struct RawSequences {                 // a one-shot search's inputs: the caller's ASCII in device memory
     const unsigned char* seq1;
     int                  n;
@@ -1011,6 +1078,7 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
         a.sel[1].bounds = bound_params(*ts2->t, s.m);
     }
     a.fused = fused ? 1 : 0;
+    if (!deal_single(c, p.class_chars, a.wave_lo, a.wave_hi)) { set_last_error("internal: no deal of the symbol stream"); return PSA_ERR_STATE; }
     a.lds_bytes = p.lds_bytes;
     a.tail = rescore_args(c, s, (long long)span * s.m, ts);
     a.tail.record_out = c->record_out;
@@ -1110,6 +1178,7 @@ psa_status launch_count_duo(psa_context* c, const unsigned* s2cls, size_t s2_str
     a.span = last - first;
     a.skew_ticks = (unsigned)c->duo_skew_ticks;
     a.spin_limit = c->duo_force_timeout ? 0 : (1 << 21);
+    if (!deal_duo(c, a.class_chars, a.wave_lo, a.wave_hi)) { set_last_error("internal: no deal of the symbol stream"); return PSA_ERR_STATE; }
     a.bad = c->d_bad;
     for (int k = 0; k < 2; ++k) {
         const int src = k < nmodes ? k : 0;
@@ -1342,6 +1411,12 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     // Experiment / fault-injection knobs: only in the debug library (libpsa_debug.so, -DPSA_EXPERIMENT);
     // the product library reads no environment variable except PSA_DEVICE (legacy entry point).
     if (const char* r = std::getenv("PSA_SEQ_R")) c->forced_r = std::atoi(r);
+    if (const char* r = std::getenv("PSA_DUO_OLDER")) c->duo_older_permille = std::max(0, std::min(1000, std::atoi(r)));
+    if (const char* r = std::getenv("PSA_DEAL")) {              // e.g. 375,250,250,125: permille by age, oldest first
+        int v[4] = {0, 0, 0, 0};
+        if (std::sscanf(r, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4)
+            for (int g = 0; g < 4; ++g) c->single_deal[g] = v[g];
+    }
     if (const char* r = std::getenv("PSA_BATCH_STREAMS")) c->batch_streams = std::atoi(r) >= 2 ? 2 : 1;
     if (const char* r = std::getenv("PSA_RESCORE_GRID")) c->batch_rescore_grid = std::max(1, std::min(1024, std::atoi(r)));
     if (const char* r = std::getenv("PSA_RESCORE_PAD")) c->rescore_pad = std::atoi(r) != 0;

@@ -372,15 +372,17 @@ __device__ __forceinline__ void shift_planes(Counter (&cnt)[2][kCounters], unsig
         }
 }
 
-// The main loop of one wave: `nclasses` shift classes of `class_chars` chars each (a multiple of
-// kUnroll), highest class first.  `sym` = the wave's symbols in that order (class_index), `lane_base`
-// = LDS byte address of slot `lane` of the chunk's first column.  On return cnt holds, for the wave's
-// classes, sum_J D_J[x + J - low_class] ... shifted down by `low_class`: the wave's share of the counts.
+// The main loop of one wave: `chars` consecutive chars (a multiple of kUnroll) of the workgroup's class-ordered
+// symbol stream (class_index: class 31 first, `class_chars` chars per class), starting at char `first_k` of a class —
+// a wave's share need not be whole classes (the hardware does not treat the waves of a SIMD alike, see the kernels'
+// deals).  `sym` = the symbols from the share's first char on, `lane_base` = LDS byte address of slot `lane` of the
+// chunk's first column, `low_class` = the lowest class the share touches.  On return cnt holds the share's part of
+// sum_J D_J[x + J], shifted down: the wave's contribution to the counts.
 template <typename Counter, typename RowOf>
-__device__ __forceinline__ void count_classes(Counter (&cnt)[2][kCounters],
-                                              const __attribute__((address_space(4))) unsigned* sym,
-                                              int nclasses, int class_chars, unsigned low_class,
-                                              unsigned lane_base, int lane, RowOf row_of)
+__device__ __forceinline__ void count_stream(Counter (&cnt)[2][kCounters],
+                                             const __attribute__((address_space(4))) unsigned* sym,
+                                             int first_k, int chars, int class_chars, unsigned low_class,
+                                             unsigned lane_base, int lane, RowOf row_of)
 {
     // the row offsets of a round are fetched one round ahead, the LDS slots one char ahead;
     // the last prefetches of a wave run past its range into valid padding and are never used
@@ -391,13 +393,17 @@ __device__ __forceinline__ void count_classes(Counter (&cnt)[2][kCounters],
     for (int q = 0; q < kUnroll; ++q) rowoff_a[q] = row_of(sym[q]);
     unsigned lane_addr;
     SlotRegs cur;
-    for (int c = 0; c < nclasses; ++c) {
-        if (c) shift_planes(cnt, 1u, lane);              // Horner step: C[x] <- C[x+1], then add the next class
-        lane_addr = lane_base;
+    bool first = true;
+    while (chars > 0) {
+        const int room = class_chars - first_k;
+        const int n = chars < room ? chars : room;       // this class's part of the share
+        if (!first) shift_planes(cnt, 1u, lane);         // Horner step: C[x] <- C[x+1], then add the next class
+        first = false;
+        lane_addr = lane_base + 8u * (unsigned)first_k;
         lds_issue<0>(cur, lane_addr + rowoff_a[0]);
         lds_retire(cur);
         int g = 0;
-        for (; g + 2 * kUnroll <= class_chars; g += 2 * kUnroll) {
+        for (; g + 2 * kUnroll <= n; g += 2 * kUnroll) {
             sym += kUnroll;
 #pragma unroll
             for (int q = 0; q < kUnroll; ++q) rowoff_b[q] = row_of(sym[q]);   // wave-uniform
@@ -408,7 +414,7 @@ __device__ __forceinline__ void count_classes(Counter (&cnt)[2][kCounters],
             class_round<kJoin, 8 * kUnroll>(cnt, cur, rowoff_b, rowoff_a[0], lane_addr, std::make_integer_sequence<int, kUnroll>{});
             lane_addr += 16u * kUnroll;
         }
-        if (g < class_chars) {                           // a class's odd last round
+        if (g < n) {                                     // an odd last round
             sym += kUnroll;
 #pragma unroll
             for (int q = 0; q < kUnroll; ++q) rowoff_b[q] = row_of(sym[q]);
@@ -416,8 +422,29 @@ __device__ __forceinline__ void count_classes(Counter (&cnt)[2][kCounters],
 #pragma unroll
             for (int q = 0; q < kUnroll; ++q) rowoff_a[q] = rowoff_b[q];
         }
+        chars -= n;
+        first_k = 0;
     }
     if (low_class) shift_planes(cnt, low_class, lane);
+}
+
+// A wave's share [lo, hi) of the stream in rounds of kUnroll chars -> count_stream's arguments
+struct WaveShare {
+    int sym_at;        // first symbol of the share (offset into the chunk's stream)
+    int first_k;       // char inside its first class
+    int chars;
+    unsigned low_class;
+};
+__device__ __forceinline__ WaveShare wave_share(int lo_round, int hi_round, int class_chars)
+{
+    WaveShare s;
+    s.sym_at = lo_round * kUnroll;
+    s.chars = (hi_round - lo_round) * kUnroll;
+    const int cls0 = s.sym_at / class_chars;
+    s.first_k = s.sym_at - cls0 * class_chars;
+    const int last = s.chars > 0 ? (hi_round * kUnroll - 1) / class_chars : cls0;
+    s.low_class = (unsigned)(kClasses - 1 - last);
+    return s;
 }
 
 // ---- counter planes -> integer counts, summed over the waves in LDS ----------------
@@ -1459,6 +1486,7 @@ struct CountArgs {
     // Single searches are ONE launch: the last tile workgroup to finish its selection ends the search (finish_search:
     // final bound, surviving candidates, exact re-score, fold, tail).  `tail` = what psa_rescore_kernel would be given.
     int         fused;
+    unsigned short wave_lo[16], wave_hi[16];   // every wave's share of the chunk's symbol stream, in rounds of kUnroll chars
     int         lds_bytes;            // dynamic LDS of the launch (the tail carves its buffers out of the dead planes)
     // psa_count_kernel<16, true> (one-shot searches from raw ASCII, no encode launch in front): the caller's sequences;
     // every workgroup converts Seq1's window while it builds the planes and writes Seq2's class-ordered symbols itself
@@ -1666,14 +1694,20 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         for (int k = 0; k < kCounters; ++k) cnt[w][k].clear();
 
     // this wave's shift classes: low_class .. low_class + kWaveClasses - 1, walked from the top down
-    constexpr int kWaveClasses = kClasses / WAVES;
-    const int low_class = wave * kWaveClasses;
+    // The hardware favours the oldest wave of a SIMD (waves w, w+4, w+8, w+12 share one), so with equal shares the oldest
+    // finishes 25 us before the youngest and the SIMD ends on one wave that cannot fill its issue slots.  `skew` (host:
+    // when three classes fit a wave's counters) deals 3 / 2 / 2 / 1 classes to the four ages instead of 2 / 2 / 2 / 2.
+    // this wave's share of the chunk's symbol stream (host: deal_single — the hardware favours the oldest wave of a
+    // SIMD, so the shares differ by age)
+    const int class_chars_u = __builtin_amdgcn_readfirstlane(a.class_chars);
+    const WaveShare share = wave_share(__builtin_amdgcn_readfirstlane((int)a.wave_lo[wave]),
+                                       __builtin_amdgcn_readfirstlane((int)a.wave_hi[wave]), class_chars_u);
     // constant address space: keeps these wave-uniform loads scalar (s_load) although the loop
     // contains volatile asm
     using const_u32 = const __attribute__((address_space(4))) unsigned;
     // (32-bit index arithmetic: a 64-bit multiply would go through the VALU and make these vector loads)
-    const int class_chars = __builtin_amdgcn_readfirstlane(a.class_chars);    // (loaded under a divergent branch above)
-    const int sym_at = __builtin_amdgcn_readfirstlane(((int)blockIdx.y * kClasses + (kClasses - kWaveClasses - low_class)) * class_chars);
+    const int class_chars = class_chars_u;
+    const int sym_at = __builtin_amdgcn_readfirstlane((int)blockIdx.y * kClasses * class_chars + share.sym_at);
     const_u32* sym = (const_u32*)(size_t)(a.classes + sym_at);
     if constexpr (RAW) {
         // the symbols were stored in this launch (behind the barrier above): drop what the scalar cache holds, and tie
@@ -1681,7 +1715,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         asm volatile("s_dcache_inv\n\ts_waitcnt lgkmcnt(0)" : "+s"(sym) : : "memory");
     }
     const unsigned lane_base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds + (unsigned)lane * 8u;
-    count_classes(cnt, sym, kWaveClasses, class_chars, (unsigned)low_class, lane_base, lane, row_of);
+    count_stream(cnt, sym, share.first_k, share.chars, class_chars, share.low_class, lane_base, lane, row_of);
 
     // ---- epilogue: every wave turns its counter planes into integers (bit-matrix transpose in
     // registers, two 16-bit counts per dword) and adds them to the tile's cells in LDS (ds_add_u32);
@@ -1834,6 +1868,7 @@ struct DuoArgs {
     int first, lead, span;
     unsigned skew_ticks;  // 100 MHz ticks group 1 waits before its first query
     int spin_limit;       // polls a group barrier waits before it gives up (debug library: 0 forces the give-up path)
+    unsigned short wave_lo[8], wave_hi[8];   // the shares of a group's eight waves of a query's symbol stream, in rounds
     int* bad;             // |= 4 if a group barrier timed out (never expected): the host redoes the batch without this kernel
     struct Select {
         char*   scalars;      // search scalars of the launch's first query (kScalStride apart)
@@ -1946,13 +1981,14 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
         for (int w = 0; w < 2; ++w)
 #pragma unroll
             for (int k = 0; k < kCounters; ++k) cnt[w][k].clear();
-        constexpr int kWaveClasses = kClasses / kDuoGroupWaves;
-        const int low_class = gw * kWaveClasses;
+        // this wave's share of the query's symbol stream (host: deal_duo)
         const int class_chars = __builtin_amdgcn_readfirstlane(a.class_chars);
-        const int sym_at = __builtin_amdgcn_readfirstlane((kClasses - kWaveClasses - low_class) * class_chars);   // scalar unit
+        const WaveShare share = wave_share(__builtin_amdgcn_readfirstlane((int)a.wave_lo[gw]),
+                                           __builtin_amdgcn_readfirstlane((int)a.wave_hi[gw]), class_chars);
+        const int sym_at = __builtin_amdgcn_readfirstlane(share.sym_at);   // scalar unit
         const_u32* sym = (const_u32*)(size_t)(a.classes + (size_t)q * a.s2_stride + sym_at);
-        count_classes(cnt, sym, kWaveClasses, class_chars, (unsigned)low_class, lds_base + (unsigned)lane * 8u, lane,
-                      [](unsigned sym_off) { return sym_off; });
+        count_stream(cnt, sym, share.first_k, share.chars, class_chars, share.low_class, lds_base + (unsigned)lane * 8u, lane,
+                     [](unsigned sym_off) { return sym_off; });
 
         PSA_DPHASE(1);
         // the epilogue is a chain of short, latency-bound steps: let its instructions pass the other group's main loop
