@@ -419,7 +419,11 @@ struct psa_context {
     int         n_cap = 0;
 
     unsigned char* d_raw = nullptr;  size_t raw_cap = 0;   // staging for host sequences
-    size_t         raw_second = 0;        // stage_host_pair: where the second sequence starts in d_raw
+    // pinned, host-coherent staging of a search's two sequences: the host copies them in (85 GB/s), the encode kernel reads
+    // them over PCIe itself — 12 + 25 us for 1 MB instead of the 46 us of a pageable hipMemcpyAsync (tools/ubench/h2d.hip)
+    unsigned char* h_stage = nullptr;  size_t stage_cap = 0;
+    unsigned char* hd_stage = nullptr;    // its device-side alias
+    size_t         stage_second = 0;
     unsigned char* d_s1 = nullptr;        // Seq1 codes, code-27 padded to n_cap
     int            nslots = 0;            // 32-symbol slots of d_s1
     double*        d_pair = nullptr;
@@ -654,7 +658,7 @@ psa_status encode_seq2(psa_context* c, SearchSlot& s, const void* d_raw, int m, 
     psa::Seq2Args a;
     FilterPlan p;
     PSA_TRY(seq2_args(s, d_raw, m, c->n, c->d_bad, &a, &p));
-    hipLaunchKernelGGL(psa::psa_encode_seq2_kernel, dim3((s.m_cap + 255) / 256), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(psa::psa_encode_seq2_kernel, dim3((s.m_cap / 16 + 255) / 256), dim3(256), 0, stream, a);
     PSA_HIP(hipGetLastError());
     seq2_encoded(s, m, p);
     return PSA_OK;
@@ -669,7 +673,7 @@ psa_status encode_pair(psa_context* c, const void* d_raw1, int n, const void* d_
     FilterPlan p;
     PSA_TRY(seq1_args(c, d_raw1, n, &a1));
     PSA_TRY(seq2_args(s, d_raw2, m, n, c->d_bad, &a2, &p));
-    const int blocks1 = (c->nslots + 255) / 256, blocks2 = (s.m_cap + 255) / 256;
+    const int blocks1 = (c->nslots + 255) / 256, blocks2 = (s.m_cap / 16 + 255) / 256;
     hipLaunchKernelGGL(psa::psa_encode_pair_kernel, dim3(blocks1 + blocks2), dim3(256), 0, c->stream, a1, a2, blocks1);
     PSA_HIP(hipGetLastError());
     c->n = n;
@@ -701,25 +705,29 @@ psa_status stage_host(psa_context* c, const char* host, size_t len)
     return PSA_OK;
 }
 
-// Both sequences into the staging buffer.  Sequences that lie close together in host memory (the two arrays of a
-// ProgramData) travel as ONE copy command, gap included; raw_second = where the second one starts in d_raw.
-psa_status stage_host_pair(psa_context* c, const char* a, size_t na, const char* b, size_t nb)
+// Both sequences of a search into the pinned staging buffer (host memcpy); the encode kernel reads them from there.
+// Sequences that lie close together in host memory (the two arrays of a ProgramData) keep their distance, so the copy is
+// one memcpy when the gap is small.
+psa_status stage_pinned_pair(psa_context* c, const char* a, size_t na, const char* b, size_t nb)
 {
-    const bool adjacent = b >= a + na && (size_t)(b - a) + nb <= na + nb + 4096;
+    const bool adjacent = b >= a + na && (size_t)(b - a) <= na + 4096;
     const size_t second = adjacent ? (size_t)(b - a) : ((na + 63) & ~(size_t)63);
     const size_t len = second + nb;
-    if (len > c->raw_cap) {
-        c->raw_cap = 0;
-        PSA_TRY(dev_alloc(&c->d_raw, len + 64));
-        c->raw_cap = len + 64;
+    if (len > c->stage_cap) {
+        if (c->h_stage) PSA_HIP(hipHostFree(c->h_stage));
+        c->h_stage = c->hd_stage = nullptr;
+        c->stage_cap = 0;
+        const size_t cap = len + len / 4 + 4096;
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), cap, hipHostMallocMapped | hipHostMallocCoherent));
+        PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->hd_stage), c->h_stage, 0));
+        c->stage_cap = cap;
     }
-    if (adjacent) {
-        PSA_HIP(hipMemcpyAsync(c->d_raw, a, len, hipMemcpyHostToDevice, c->stream));
-    } else {
-        PSA_HIP(hipMemcpyAsync(c->d_raw, a, na, hipMemcpyHostToDevice, c->stream));
-        PSA_HIP(hipMemcpyAsync(c->d_raw + second, b, nb, hipMemcpyHostToDevice, c->stream));
+    if (adjacent) std::memcpy(c->h_stage, a, len);
+    else {
+        std::memcpy(c->h_stage, a, na);
+        std::memcpy(c->h_stage + second, b, nb);
     }
-    c->raw_second = second;
+    c->stage_second = second;
     return PSA_OK;
 }
 
@@ -1464,6 +1472,7 @@ void psa_destroy(psa_context* c)
     }
     for (auto& ev : c->pool_events) (void)hipEventDestroy(ev);
     if (c->h_tails) (void)hipHostFree(c->h_tails);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_bad) (void)hipHostFree(c->h_bad);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -1513,8 +1522,8 @@ psa_status psa_set_seq1(psa_context* c, const char* seq1, int n)
     if (!c || !seq1 || n < 1) { set_last_error("psa_set_seq1: bad arguments"); return PSA_ERR_ARG; }
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
-    PSA_TRY(stage_host(c, seq1, (size_t)n));
-    PSA_TRY(encode_seq1(c, c->d_raw, n));
+    PSA_TRY(stage_pinned_pair(c, seq1, (size_t)n, seq1 + n, 0));
+    PSA_TRY(encode_seq1(c, c->hd_stage, n));                // reads the pinned host copy over PCIe
     PSA_TRY(check_bad_now(c));
     return report_bad(c);
 }
@@ -1524,8 +1533,8 @@ psa_status psa_set_seq2(psa_context* c, const char* seq2, int m)
     if (!c || !seq2 || m < 1) { set_last_error("psa_set_seq2: bad arguments"); return PSA_ERR_ARG; }
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
-    PSA_TRY(stage_host(c, seq2, (size_t)m));
-    PSA_TRY(encode_seq2(c, c->slot[0], c->d_raw, m, c->stream));
+    PSA_TRY(stage_pinned_pair(c, seq2, (size_t)m, seq2 + m, 0));
+    PSA_TRY(encode_seq2(c, c->slot[0], c->hd_stage, m, c->stream));
     PSA_TRY(check_bad_now(c));
     return report_bad(c);
 }
@@ -1544,8 +1553,8 @@ psa_status psa_set_sequences(psa_context* c, const char* seq1, int n, const char
     if (!c || !seq1 || !seq2 || n < 1 || m < 1) { set_last_error("psa_set_sequences: bad arguments"); return PSA_ERR_ARG; }
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
-    PSA_TRY(stage_host_pair(c, seq1, (size_t)n, seq2, (size_t)m));
-    PSA_TRY(encode_pair(c, c->d_raw, n, c->d_raw + c->raw_second, m));
+    PSA_TRY(stage_pinned_pair(c, seq1, (size_t)n, seq2, (size_t)m));
+    PSA_TRY(encode_pair(c, c->hd_stage, n, c->hd_stage + c->stage_second, m));     // reads the host copy over PCIe
     PSA_TRY(check_bad_now(c));
     return report_bad(c);
 }
@@ -2033,6 +2042,8 @@ psa_status psa_search_batch(psa_context* c, const char* queries, int nq, int m, 
     if (!c || !queries || nq < 1 || stride < (size_t)m) { set_last_error("psa_search_batch: bad arguments"); return PSA_ERR_ARG; }
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
+    // (a DMA copy, not the pinned staging the single-search setters use: the batch encode kernel reads its queries a byte
+    // per lane, which over PCIe would be a request per byte)
     PSA_TRY(stage_host(c, queries, (size_t)(nq - 1) * stride + (size_t)m));
     PSA_HIP(hipStreamSynchronize(c->stream));
     return batch_impl(c, c->d_raw, nq, m, stride, first, last, results, nullptr);
@@ -2687,13 +2698,13 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
         }
         psa_context* c = g_legacy_ctx;
         if (psa_set_weights(c, weights, is_max) != PSA_OK) legacy_die("Failed to build the score tables");
-        // The two arrays of a ProgramData lie side by side: one copy command (the reference copies the whole struct,
-        // cuda_funcs.cu:50) and ONE launch that reads the ASCII itself; the alphabet flag comes back with the result
-        // tail.
-        if (n < 1 || ensure_device(c) != PSA_OK || stage_host_pair(c, seq1, (size_t)n, seq2, (size_t)m) != PSA_OK)
+        // The two arrays of a ProgramData lie side by side: one host memcpy into pinned staging (the reference copies the
+        // whole struct, cuda_funcs.cu:50), an encode launch that reads it over PCIe, one search launch; the alphabet flag
+        // comes back with the result tail.
+        if (n < 1 || ensure_device(c) != PSA_OK || stage_pinned_pair(c, seq1, (size_t)n, seq2, (size_t)m) != PSA_OK ||
+            encode_pair(c, c->hd_stage, n, c->hd_stage + c->stage_second, m) != PSA_OK)
             legacy_die("Failed to copy data from host to device");
-        if (psa_search_device(c, c->d_raw, n, c->d_raw + c->raw_second, m, first_offset, last_offset, &r) != PSA_OK)
-            legacy_die("Failed to run the search");
+        if (psa_search(c, first_offset, last_offset, &r) != PSA_OK) legacy_die("Failed to run the search");
     }
     if (r.offset < 0 || r.ch == 0) return none;   // cuda_funcs.cu:143-144
     returned_mutant->offset = r.offset;

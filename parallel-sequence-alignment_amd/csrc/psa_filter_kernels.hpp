@@ -236,31 +236,59 @@ struct Seq2Args {
     int class_chars, class_total;   // the chunking the class order is laid out for
 };
 
-__device__ __forceinline__ void encode_seq2_char(const Seq2Args& a, int i)
+// sixteen chars per thread: the ASCII is read 16 bytes at a time (the sequence may lie in pinned HOST memory, where
+// every load is a PCIe request), the byte codes and row offsets are stored as whole vectors
+__device__ __forceinline__ void encode_seq2_16(const Seq2Args& a, int i0)
 {
-    if (i >= a.capacity) return;
-    int code = kCodePad;
-    if (i < a.m) {
-        const unsigned char c = a.raw[i];
-        code = (c >= 'A' && c <= 'Z') ? c - 'A' : (c == '-' ? kCodeHyphen : kCodeBad);
-        if (code == kCodeBad) { atomicOr(a.bad, 2); code = kCodePad; }
+    if (i0 >= a.capacity) return;                        // (capacity is a multiple of 64)
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (i0 < a.m) {
+        if (i0 + 16 <= a.m && ((reinterpret_cast<size_t>(a.raw) + (size_t)i0) & 15) == 0) {
+            const uint4 q = *reinterpret_cast<const uint4*>(a.raw + i0);
+            w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (i0 + 4 * q + r < a.m) w[q] |= (unsigned)a.raw[i0 + 4 * q + r] << (8 * r);
+        }
     }
-    a.rows[i] = (unsigned int)code << kRowShift;    // symbol as a 4 KiB row offset; the sequential engine
-    a.bytes[i] = (unsigned char)code;               // shifts it back to a table row
-    if (i < a.class_total) a.classes[class_index(i, a.class_chars)] = (unsigned int)code << kRowShift;
-    else if (i < a.class_total + kUnroll) a.classes[i] = (unsigned int)kCodePad << kRowShift;
+    unsigned codes[4];
+    bool any_bad = false;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        codes[q] = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = i0 + 4 * q + r;
+            const unsigned c = (w[q] >> (8 * r)) & 0xffu;
+            unsigned code = kCodePad;
+            if (i < a.m) {
+                code = c - 'A' < 26u ? c - 'A' : (c == (unsigned)'-' ? (unsigned)kCodeHyphen : (unsigned)kCodePad);
+                any_bad |= code == (unsigned)kCodePad;
+            }
+            codes[q] |= code << (8 * r);
+            a.rows[i] = code << kRowShift;               // symbol as a 4 KiB row offset; the sequential engine shifts it back
+            // the same symbols in the count kernels' class order (class_index); kUnroll entries of padding behind them
+            if (i < a.class_total) a.classes[class_index(i, a.class_chars)] = code << kRowShift;
+            else if (i < a.class_total + kUnroll) a.classes[i] = (unsigned)kCodePad << kRowShift;
+        }
+    }
+    *reinterpret_cast<uint4*>(a.bytes + i0) = make_uint4(codes[0], codes[1], codes[2], codes[3]);
+    if (any_bad) atomicOr(a.bad, 2);
 }
 
 __global__ __launch_bounds__(256) void psa_encode_seq2_kernel(Seq2Args a)
 {
-    encode_seq2_char(a, blockIdx.x * 256 + threadIdx.x);
+    encode_seq2_16(a, (blockIdx.x * 256 + threadIdx.x) * 16);
 }
 
 // both sequences of a search in ONE launch (psa_set_sequences*, gpu_run_program): blocks [0, blocks1) take Seq1
 __global__ __launch_bounds__(256) void psa_encode_pair_kernel(PrepareArgs a1, Seq2Args a2, int blocks1)
 {
     if ((int)blockIdx.x < blocks1) prepare_seq1_slot(a1, blockIdx.x * 256 + threadIdx.x);
-    else encode_seq2_char(a2, ((int)blockIdx.x - blocks1) * 256 + threadIdx.x);
+    else encode_seq2_16(a2, (((int)blockIdx.x - blocks1) * 256 + threadIdx.x) * 16);
 }
 
 // out[b] bit t = in[t] bit b  (recursive block swap, Hacker's Delight 7-3, mirrored)
