@@ -1283,12 +1283,12 @@ bool use_filter(const psa_context* c, int first, int last, int m)
     FilterPlan p;
     if (!plan_filter(first, last, m, &p)) return false;      // Seq2 beyond what the count kernels chunk
     if (c->engine == PSA_ENGINE_FILTER) return true;
-    // Measured on MI355X (tools/engine_threshold.py, round 2 kernels), microseconds per blocking search: the
-    // sequential engine is a serial chain of m additions per lane, the filter engine has the larger fixed cost
-    // (two kernels, plane build, epilogue) and ~16x the throughput.
+    // Measured on MI355X (tools/engine_threshold.py, round 3 kernels: gpurun_out/engine_threshold_r3.txt), microseconds
+    // per blocking search: the sequential engine is a serial chain of m additions per lane, the filter engine has the
+    // larger fixed cost (plane build, epilogue, the search's tail) and ~30x the throughput.
     const double pairs = (double)(last - first) * m;
-    const double t_sequential = 22.0 + 0.034 * m + pairs / 8.5e6;
-    const double t_filter = 42.0 + 0.0037 * m + pairs / 1.4e8;
+    const double t_sequential = 16.0 + 0.034 * m + pairs / 8.5e6;
+    const double t_filter = 36.0 + 0.002 * m + pairs / 2.6e8;
     return t_filter < t_sequential;
 }
 
