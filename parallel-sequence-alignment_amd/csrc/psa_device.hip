@@ -402,6 +402,7 @@ struct psa_context {
     // 250 -> 16.3 ms, 625 -> slower still; per 32-query launch 375 2.006 ms, 350 2.04, 400 2.07, 325 2.09, 425 2.10, 450 2.11
     // (shares that split a class pay a counter shift and a restart more)
     int  duo_older_permille = 375;
+    int  duo_prio_mode = 0;            // debug library: other s_setprio schemes of the batch kernel's main loop
     bool granted_duo = false;
     bool duo = true;                   // batches: one workgroup per tile serves several queries (psa_count_duo_kernel)
     int  duo_queries = 128;            // queries per launch of it (measured: 32 -> 128 per launch -1.1 % per 256-query batch;
@@ -1186,6 +1187,7 @@ psa_status launch_count_duo(psa_context* c, const unsigned* s2cls, size_t s2_str
     a.span = last - first;
     a.skew_ticks = (unsigned)c->duo_skew_ticks;
     a.spin_limit = c->duo_force_timeout ? 0 : (1 << 21);
+    a.prio_mode = c->duo_prio_mode;
     if (!deal_duo(c, a.class_chars, a.wave_lo, a.wave_hi)) { set_last_error("internal: no deal of the symbol stream"); return PSA_ERR_STATE; }
     a.bad = c->d_bad;
     for (int k = 0; k < 2; ++k) {
@@ -1419,6 +1421,7 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     // Experiment / fault-injection knobs: only in the debug library (libpsa_debug.so, -DPSA_EXPERIMENT);
     // the product library reads no environment variable except PSA_DEVICE (legacy entry point).
     if (const char* r = std::getenv("PSA_SEQ_R")) c->forced_r = std::atoi(r);
+    if (const char* r = std::getenv("PSA_DUO_PRIO")) c->duo_prio_mode = std::atoi(r);
     if (const char* r = std::getenv("PSA_DUO_OLDER")) c->duo_older_permille = std::max(0, std::min(1000, std::atoi(r)));
     if (const char* r = std::getenv("PSA_DEAL")) {              // e.g. 375,250,250,125: permille by age, oldest first
         int v[4] = {0, 0, 0, 0};

@@ -1897,6 +1897,7 @@ struct DuoArgs {
     unsigned skew_ticks;  // 100 MHz ticks group 1 waits before its first query
     int spin_limit;       // polls a group barrier waits before it gives up (debug library: 0 forces the give-up path)
     unsigned short wave_lo[8], wave_hi[8];   // the shares of a group's eight waves of a query's symbol stream, in rounds
+    int prio_mode;        // 0: the younger waves of a group at the higher priority (product); 1-3: experiments
     int* bad;             // |= 4 if a group barrier timed out (never expected): the host redoes the batch without this kernel
     struct Select {
         char*   scalars;      // search scalars of the launch's first query (kScalStride apart)
@@ -1996,6 +1997,9 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
         // long before the others and wait for them at the first epilogue barrier
         {
             int prio = (gw >> 1) + group;          // and the younger group a notch above the older one
+            if (a.prio_mode == 1) prio = 0;                                   // experiment: no priorities in the main loop
+            else if (a.prio_mode == 2) prio = 3 - (gw >> 1) - group;          // experiment: the older waves first
+            else if (a.prio_mode == 3) prio = (gw >> 2) + group;              // experiment: two levels per group
             switch (prio) {
             case 0: __builtin_amdgcn_s_setprio(0); break;
             case 1: __builtin_amdgcn_s_setprio(1); break;
