@@ -2456,6 +2456,24 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
     DeviceScope device_scope;
     const int total = last - first;
     std::vector<int> lo((size_t)ndev), hi((size_t)ndev), tag((size_t)ndev);
+    // whatever happens below, no context is left with a search "in flight" (an error half-way would otherwise block
+    // the next call on the devices that had been started)
+    struct Settle {
+        psa_group* g;
+        ~Settle()
+        {
+            for (psa_context* c : g->ctx) {
+                if (c->pending) {
+                    (void)hipSetDevice(c->device);
+                    (void)hipStreamSynchronize(c->stream);
+                    c->slot[0].scal_dirty = true;
+                }
+                c->pending = false;
+                c->record_out = nullptr;
+                c->record_shard = -1;
+            }
+        }
+    } settle_on_exit{g};
     for (int i = 0; i < ndev; ++i) {
         psa_context* c = g->ctx[i];
         psa_shard_range(total, ndev, i, &lo[i], &hi[i]);

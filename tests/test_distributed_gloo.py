@@ -60,6 +60,46 @@ def test_shard_exchange_fold(oracle, psa, reference_records, world, rec):
         assert got[5] == total * len(s2)
 
 
+def _many_worker(rank, world, port, case, out):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import psa_amd as psa
+    import bench
+    from oracle import oracle
+    w, s1, queries, is_max = case
+    mine = []
+    for q, s2 in enumerate(queries):
+        total = len(s1) - len(s2) + 1
+        lo, hi = psa.shard_range(total, world, rank)
+        score, off, ci, ch = oracle.search(s1, s2, w, is_max, lo, hi, threads=1)
+        rec = psa.Result()
+        rec.score, rec.offset, rec.char_offset, rec.ch, rec.shard, rec.pairs = score, off, ci, ord(ch), rank, (hi - lo) * len(s2)
+        mine.append(rec)
+    got = bench.exchange_and_fold_many(psa, dist, torch, mine, rank, world, is_max, torch.device("cpu"))
+    out[rank] = [(g.score, g.offset, g.char_offset, chr(g.ch), g.pairs) for g in got]
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_throughput_mode_shard_exchange_fold(oracle, psa, world):
+    """bench.py --mode shard --queries Q: every rank holds one record per query for ITS offset shard; one all-reduce
+    of the world x Q records, then the is_swapable fold per query (cpu_funcs.c:71-94) gives the full-range answers."""
+    s1 = psa.generate_sequence(311, 2500)
+    queries = [psa.generate_sequence(420 + q, 48) for q in range(4)]
+    queries[2] = s1[700:748]                                   # an exact copy: its shard must win
+    w = [1.5, 2.6, 0.3, 0.2]
+    want = [oracle.search(s1, q, w, False, threads=2) + ((len(s1) - len(q) + 1) * len(q),) for q in queries]
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_many_worker, args=(world, _free_port(), (w, s1, queries, False), out), nprocs=world, join=True)
+    for rank in range(world):
+        assert out[rank] == want
+
+
 def _batch_worker(rank, world, port, case, out):
     for p in (ROOT, PKG):
         if p not in sys.path:

@@ -738,6 +738,41 @@ def test_bench_n_rank_paths_rehearsed_on_one_gpu(psa, extra):
         assert line["config"]["queries_per_step"] == (32 if extra[1] == "weak" else 16)
 
 
+def test_bench_line_carries_the_contract(psa):
+    """`python bench.py` on one GPU: ONE JSON line with the driver's fields, `roofline` and (without --no-cpu-baseline)
+    `cpu_baseline`, the reference's timed region next to `value`, the health counters in `verified`, both engines, the
+    emulated offset shard and the low-entropy workload — and exit code 0 (the self-check passed)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--queries", "64",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "verified", "timed_region_8d", "single_search",
+                "sequential_engine", "shard_emulation", "low_entropy_acgt"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("valu", "hbm") and {"achieved", "peak", "unit", "frac", "traffic"} <= set(r)
+    assert r["frac"] is None or 0.3 < r["frac"] < 1.0
+    if r["frac"] is None:
+        assert "frac_withheld" in r            # the committed counters are of other kernel sources, and the line says so
+    v = d["verified"]
+    assert v["query0_max_equals_golden"] and v["query0_min_equals_golden"] and v["duo_retries"] == 0
+    assert v["sequential_engine_fallbacks"] == 0 and v["batch_equals_single_search_queries"] > 0
+    assert d["sequential_engine"]["equals_filter_engine"]
+    assert set(d["shard_emulation"]["blocking_search_us_per_rank"]) == {"1", "2", "4", "8"}
+    assert d["low_entropy_acgt"]["max"]["fallbacks"] == 0 and d["low_entropy_acgt"]["min"]["fallbacks"] == 0
+    assert d["value"] > 1e14 and d["timed_region_8d"]["value"] > 1e14
+    assert d["single_search_latency_ms"] < 0.2 and d["gpu_run_program_latency_ms"] < 0.3
+
+
 @pytest.mark.parametrize("n,m,nq", [(9711, 2131, 37), (10000, 5000, 8), (30000, 700, 101), (4100, 33, 257)])
 def test_batches_of_reference_sized_inputs_spread_over_query_blocks(psa, oracle, n, m, nq):
     """Few offset tiles (the reference's own sizes: |Seq1| <= 10,000): the batch kernel's grid is tiles x query
