@@ -738,6 +738,31 @@ __device__ __forceinline__ long long wave_scan_inclusive(long long v)
     return v;
 }
 
+// Maximum of an unsigned 64-bit value over the 64 lanes, the same DPP steps as the scan (lanes without a source
+// take 0, the identity); every lane gets the result.  (A __shfl_xor butterfly moves 64-bit values through the LDS
+// crossbar: twelve ds_bpermute round trips instead of twelve DPP moves.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_max_u64(unsigned long long v)
+{
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(v >> 32), CTRL, ROW_MASK, 0xf, false);
+    const unsigned long long o = ((unsigned long long)hi << 32) | lo;
+    return o > v ? o : v;
+}
+
+__device__ __forceinline__ long long readlane64(long long v, int l);
+
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long v)
+{
+    v = dpp_max_u64<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_max_u64<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_max_u64<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_max_u64<0x118, 0xf>(v);   // row_shr:8   -> lane 15 of every row holds the row's maximum
+    v = dpp_max_u64<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v = dpp_max_u64<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+    return (unsigned long long)readlane64((long long)v, 63);
+}
+
 __device__ __forceinline__ long long readlane64(long long v, int l)
 {
     const unsigned lo = __builtin_amdgcn_readlane((int)v, l);
@@ -1403,11 +1428,7 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
             unsigned long long key = 0ull;
             classify_chars<RAW>(r.s1 + s_surv[base + j], r.s2, s_clsrank, s_codes + (size_t)j * region, 0, m, tid, T, key,
                                 r.n1 - s_surv[base + j], m);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const unsigned long long other = __shfl_xor(key, d, 64);
-                key = other > key ? other : key;
-            }
+            key = wave_max_u64(key);
             if (lane == 0) s_keys[j * WAVES + wave] = key;
         }
         __syncthreads();
@@ -1424,11 +1445,7 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
             unsigned char* mine = s_codes + (size_t)wave * region;
             // the best delta rank and its first char; the two symbols there are asked for now and used after the sum
             unsigned long long key = lane < WAVES ? s_keys[wave * WAVES + lane] : 0ull;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const unsigned long long other = __shfl_xor(key, d, 64);
-                key = other > key ? other : key;
-            }
+            key = wave_max_u64(key);
             const int rank = (int)(key >> 32);
             const int first_i = rank ? (int)(0xffffffffu - (unsigned)(key & 0xffffffffu)) : 0;
             unsigned sym2 = r.s2[first_i], sym1 = r.s1[o + first_i];
@@ -1535,7 +1552,8 @@ struct CountArgs {
 template <int WAVES, bool RAW = false>
 __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
 {
-    extern __shared__ uint2 lds[];                  // [kMaskRows][lds_slots]; reused by the epilogue
+    extern __shared__ __attribute__((aligned(16))) uint2 lds[];   // [kMaskRows][lds_slots] planes, the count cells; the tail's buffers
+                                                                  // (16-byte aligned: the tail reads its staged codes as uint4)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1808,11 +1826,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         const double pess = thread_bounds<kPer>(a.sel[mode].bounds, n, (int)blockIdx.x * kTileStride + o_local - a.lead,
                                                 a.span, kTileStride - o_local, up[mode]);
         unsigned long long key = order_key(pess);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long other = __shfl_xor(key, d, 64);
-            key = other > key ? other : key;
-        }
+        key = wave_max_u64(key);
         if (lane == 0) s_best[mode][wave] = key;
     }
     __syncthreads();
@@ -2047,11 +2061,7 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
             const double pess = thread_bounds<kDuoPer>(sel.bounds, n, (int)blockIdx.x * kTileStride + o_local - a.lead, a.span,
                                                        kTileStride - o_local, up);
             unsigned long long key = order_key(pess);
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) {
-                const unsigned long long other = __shfl_xor(key, d, 64);
-                key = other > key ? other : key;
-            }
+            key = wave_max_u64(key);
             duo_barrier(bar, bar_target, lane, a.bad, a.spin_limit);          // the previous mode's s_best has been read
             if (lane == 0) s_best[group][gw] = key;
             duo_barrier(bar, bar_target, lane, a.bad, a.spin_limit);
@@ -2173,11 +2183,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
 #endif
 
     // best rank and its first position over all chars
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long other = __shfl_xor(key, d, 64);
-        key = other > key ? other : key;
-    }
+    key = wave_max_u64(key);
     if (lane == 0) s_key[tid >> 6] = key;
     __syncthreads();
     if (tid == 0) {
