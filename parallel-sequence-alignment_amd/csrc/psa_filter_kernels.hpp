@@ -50,6 +50,14 @@ constexpr int kCounters = 3;       // n_lo, n_hi, n_both
 constexpr int kRowShift = 12;      // LDS rows of the count kernel are 4096 bytes apart (512 slots)
 constexpr int kRowSlots = 1 << (kRowShift - 3);
 
+#ifdef PSA_PHASE_TIMING
+// debug build only: 100 MHz timestamps of the count kernel's phases, [block][phase]; rows 1000.. = re-score / tail
+__device__ unsigned long long g_phase_ts[1024][8];
+#define PSA_FPHASE(k) do { if (tid == 0) g_phase_ts[1002][k] = wall_clock64(); } while (0)
+#else
+#define PSA_FPHASE(k) do { } while (0)
+#endif
+
 // ---- carry-save arithmetic on 32 independent bit lanes ----------------------
 // v_bitop3_b32 (gfx950): any 3-input boolean function, full VALU rate
 // (v_bfi_b32 and v_alignbit_b32 issue at half rate: tools/ubench/valu_rate.hip).
@@ -1187,6 +1195,12 @@ __device__ __forceinline__ bool certified_sum(const unsigned char* s_codes, int 
 {
     if (ntrue > kCertMaxTrue) return false;
     static_assert(kCertMaxTrue == 64, "one lane per true addition");
+#ifdef PSA_PHASE_TIMING
+#define PSA_SPHASE(k) do { if (lane == 0) g_phase_ts[1004][k] = wall_clock64(); } while (0)
+#else
+#define PSA_SPHASE(k) do { } while (0)
+#endif
+    PSA_SPHASE(0);
     // ---- the true additions in ascending order: every lane ranks its own entry, then all store back
     {
         const int pos = lane < ntrue ? list->ev[lane].pos : 0x7fffffff;
@@ -1200,6 +1214,7 @@ __device__ __forceinline__ bool certified_sum(const unsigned char* s_codes, int 
         }
         __builtin_amdgcn_wave_barrier();
     }
+    PSA_SPHASE(1);
     // ---- the first chars: plain chain (cpu_funcs.c:278), lanes past the end hold +0.0
     const int head = m < kCertChain ? m : kCertChain;
     ws->vals[lane] = lane < head ? s_class[s_codes[lane] & 7u] : 0.0;
@@ -1215,6 +1230,7 @@ __device__ __forceinline__ bool certified_sum(const unsigned char* s_codes, int 
         }
     }
     __builtin_amdgcn_wave_barrier();
+    PSA_SPHASE(2);
     // ---- events: event i = the interior run behind the previous true addition (or the head) + true addition i;
     // the last event (i == ntrue) is the run up to m alone.  One lane per event prepares it, then the wave applies
     // the events in order.
@@ -1267,25 +1283,33 @@ __device__ __forceinline__ bool certified_sum(const unsigned char* s_codes, int 
             }
         }
         if (__ballot(bad) != 0ull) return false;
-        // Applied in order, straight-line: mantissa + the run's integer (0 without a run: the rebuild is the identity),
-        // the checks folded into one flag, then the reference's own addition (+0.0 behind the last true addition)
+        PSA_SPHASE(3);
+        // Applied in order, straight-line: mantissa + the run's integer (0 without a run: the rebuild is the identity;
+        // its sign is the certified binade's, which the state's bits are checked against), the checks folded into one
+        // flag, then the reference's own addition (+0.0 behind the last true addition).  Two events per trip: the
+        // lane reads of the second do not wait for the first one's arithmetic.
         const int count = ntrue + 1 - i0 < 64 ? ntrue + 1 - i0 : 64;
+        const long long sdelta = (key & 0x800u) ? -(long long)delta : (long long)delta;
         bool ok = true;
-        for (int j = 0; j < count; ++j) {
+        auto apply = [&](int j) {
             const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
-            const long long dj = readlane64((long long)delta, j);
+            const long long dj = readlane64(sdelta, j);
             const double vj = __longlong_as_double(readlane64(__double_as_longlong(v), j));
             const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
-            const bool neg = (sb >> 63) != 0;
-            const long long M = (long long)((sb & 0xfffffffffffffull) | (1ull << 52));
-            const long long S = M + (neg ? -dj : dj);                        // |sum| in ulps of its binade
-            const bool run = (kj & 0x1000u) != 0u;
+            const long long S = (long long)((sb & 0xfffffffffffffull) | (1ull << 52)) + dj;    // |sum| in ulps of its binade
             // the state is in the certified binade and the run stays strictly inside it (the certificate says both)
-            ok &= !run | (((unsigned)(sb >> 52) == (kj & 0xfffu)) & (S > (1ll << 52)) & (S < (1ll << 53)));
+            ok &= ((kj & 0x1000u) == 0u) | (((unsigned)(sb >> 52) == (kj & 0xfffu)) & (S > (1ll << 52)) & (S < (1ll << 53)));
             s = __longlong_as_double((long long)((sb & 0xfff0000000000000ull) | ((unsigned long long)S & 0xfffffffffffffull))) + vj;
+        };
+        int j = 0;
+        for (; j + 2 <= count; j += 2) {
+            apply(j);
+            apply(j + 1);
         }
+        if (j < count) apply(j);
         failed = !ok;
     }
+    PSA_SPHASE(4);
     if (failed) return false;
     s_out = s;
     return true;
@@ -1318,14 +1342,6 @@ __device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const Ca
     }
     publish_tail(a.out, r, load_agent(a.bad), status, a.seq);
 }
-
-#ifdef PSA_PHASE_TIMING
-// debug build only: 100 MHz timestamps of the count kernel's phases, [block][phase]; rows 1000.. = re-score / tail
-__device__ unsigned long long g_phase_ts[1024][8];
-#define PSA_FPHASE(k) do { if (tid == 0) g_phase_ts[1002][k] = wall_clock64(); } while (0)
-#else
-#define PSA_FPHASE(k) do { } while (0)
-#endif
 
 // ---- end of a single search inside the count kernel ---------------------------------
 // Run by the last tile workgroup to arrive (all of its waves).  The candidate list is complete and the bound in

@@ -60,6 +60,10 @@ print(f"fused tail of the last search: {fc[0]} candidates listed, {fc[1]} surviv
 for k, name in enumerate(names):
     print(f"tail {name:36s} {(ft[k + 1] - ft[k]) / 100.0:7.2f} us")
 
+st = full[1004]
+for k, name in enumerate(["sort the true additions", "head: 64 chars as a plain chain", "events prepared (a lane each)", "events applied in order"]):
+    print(f"sum  {name:36s} {(st[k + 1] - st[k]) / 100.0:7.2f} us")
+
 # re-score kernel (workgroup 0, its first candidate)
 ctx.debug_rescore(np.array([r.offset, 5, 77777], dtype=np.int32))
 assert lib.psa_debug_phase_ts(buf) == 0
