@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""One rank's share of an N-way offset shard of the 1M x 10k search on this GPU (N = 1, 2, 4, 8): blocking latency and
+the launch's duration from the library's HIP events.  PSA_FILTER_CHUNKS=k (debug library) forces the chunk count."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "parallel-sequence-alignment_amd"))
