@@ -460,6 +460,7 @@ def main():
               "search_only_us": median_us(lambda: ctx.search(lo1, hi1), sync),
               "from_host_buffers_us": median_us(one_search_from_host, sync, reps=12),
               "one_shot_retries": ctx.raw_retry_count(),
+              "host_transfers_streamed": ctx.streamed_count(), "host_transfers_redone": ctx.stream_retry_count(),
               "note": "median wall time of blocking calls, device idle before each: latency = psa_search_device (raw ASCII in "
                       "HBM -> result, ONE launch: the count kernel reads the ASCII itself); encode_launch_first = "
                       "psa_set_sequences_device + psa_search (two launches), two_setters = three; search_only = the sequences "

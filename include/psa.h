@@ -132,6 +132,13 @@ psa_status psa_set_seq2_device(psa_context* ctx, const void* d_seq2, int m);
  * side by side like the two arrays of a ProgramData, one copy command). */
 psa_status psa_set_sequences(psa_context* ctx, const char* seq1, int n, const char* seq2, int m);
 psa_status psa_set_sequences_device(psa_context* ctx, const void* d_seq1, int n, const void* d_seq2, int m);
+/* Host sequences of 256 KB and more (psa_set_sequences, gpu_run_program) are STREAMED: the encode launch goes first and
+ * reads every 64 KB chunk over PCIe as soon as the host has copied it into pinned staging, so the launch latency and
+ * the host's copy run under the transfer (cuda_funcs.cu:50's cudaMemcpy of the whole ProgramData, here ~30 us per MB
+ * instead of ~46).  How many transfers went that way, and how many of those were redone the plain way because the
+ * kernel gave up waiting for the host (never expected).  ctx == NULL: the context behind gpu_run_program. */
+int psa_streamed_count(psa_context* ctx);
+int psa_stream_retry_count(psa_context* ctx);
 
 psa_status psa_set_engine(psa_context* ctx, psa_engine engine);
 /* Batches: count launches stay on one stream (default 1: no two launches overlap, a profiler sees each launch's

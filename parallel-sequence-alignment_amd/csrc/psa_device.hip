@@ -425,6 +425,16 @@ struct psa_context {
     unsigned char* h_stage = nullptr;  size_t stage_cap = 0;
     unsigned char* hd_stage = nullptr;    // its device-side alias
     size_t         stage_second = 0;
+    // Long sequences are STREAMED through it (stream_pair): the encode launch goes first and reads each chunk as soon as
+    // the host has copied and published it in this control word (pinned, host-coherent; psa_encode_pair_streamed_kernel)
+    unsigned long long* h_ctl = nullptr;
+    unsigned long long* hd_ctl = nullptr;
+    unsigned long long* d_ctl = nullptr;  // device memory: the poller workgroup forwards the host's word to it
+    unsigned       stream_ticket = 0;
+    bool           stream_force_timeout = false;   // debug library only: the host publishes nothing, the kernel gives up at once
+    int            streamed = 0;          // transfers that went that way
+    int            stream_retries = 0;    // ... and had to be redone the plain way (the kernel gave up waiting for the host)
+    bool           stream_gave_up = false; // report_bad saw that flag: the caller of stream_pair redoes the transfer
     unsigned char* d_s1 = nullptr;        // Seq1 codes, code-27 padded to n_cap
     int            nslots = 0;            // 32-symbol slots of d_s1
     double*        d_pair = nullptr;
@@ -569,6 +579,14 @@ psa_status report_bad(psa_context* c)
     if (!bad) return PSA_OK;
     PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
     *c->h_bad = 0;
+    if (bad & psa::kStreamBad) {   // the streamed encode launch gave up waiting for the host's copy: whatever it encoded is void
+        c->n = -1;
+        for (auto& s : c->slot) s.m = -1;
+        c->stream_gave_up = true;
+        c->stream_retries += 1;
+        set_last_error("internal: the encode launch gave up waiting for the host's copy");
+        return PSA_ERR_DEVICE;
+    }
     if (bad & 4) {      // (batches retry without the batch kernel first: psa_search_batch*)
         set_last_error("internal: a wave-group barrier of the batch count kernel timed out");
         return PSA_ERR_DEVICE;
@@ -706,6 +724,19 @@ psa_status stage_host(psa_context* c, const char* host, size_t len)
     return PSA_OK;
 }
 
+psa_status ensure_stage(psa_context* c, size_t len)
+{
+    if (len <= c->stage_cap) return PSA_OK;
+    if (c->h_stage) PSA_HIP(hipHostFree(c->h_stage));
+    c->h_stage = c->hd_stage = nullptr;
+    c->stage_cap = 0;
+    const size_t cap = len + len / 4 + 4096;
+    PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), cap, hipHostMallocMapped | hipHostMallocCoherent));
+    PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->hd_stage), c->h_stage, 0));
+    c->stage_cap = cap;
+    return PSA_OK;
+}
+
 // Both sequences of a search into the pinned staging buffer (host memcpy); the encode kernel reads them from there.
 // Sequences that lie close together in host memory (the two arrays of a ProgramData) keep their distance, so the copy is
 // one memcpy when the gap is small.
@@ -714,21 +745,122 @@ psa_status stage_pinned_pair(psa_context* c, const char* a, size_t na, const cha
     const bool adjacent = b >= a + na && (size_t)(b - a) <= na + 4096;
     const size_t second = adjacent ? (size_t)(b - a) : ((na + 63) & ~(size_t)63);
     const size_t len = second + nb;
-    if (len > c->stage_cap) {
-        if (c->h_stage) PSA_HIP(hipHostFree(c->h_stage));
-        c->h_stage = c->hd_stage = nullptr;
-        c->stage_cap = 0;
-        const size_t cap = len + len / 4 + 4096;
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_stage), cap, hipHostMallocMapped | hipHostMallocCoherent));
-        PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->hd_stage), c->h_stage, 0));
-        c->stage_cap = cap;
-    }
+    PSA_TRY(ensure_stage(c, len));
     if (adjacent) std::memcpy(c->h_stage, a, len);
     else {
         std::memcpy(c->h_stage, a, na);
         std::memcpy(c->h_stage + second, b, nb);
     }
     c->stage_second = second;
+    return PSA_OK;
+}
+
+// ---- long sequences from pageable host memory: the encode launch FOLLOWS the host's copy ---------------------------
+// stage_pinned_pair + encode_pair put three things one after the other: the host's copy into pinned staging (12 us per
+// MB), the launch (4 us until the kernel runs) and the kernel's reads over PCIe (25 us per MB).  Here the launch goes
+// first; the host then copies Seq1 in 64 KB chunks and publishes its progress in a control word after each, and every
+// workgroup of psa_encode_pair_streamed_kernel reads its 8 KB as soon as they are there: launch latency and copy run
+// under the PCIe transfer.  `find_nul`: Seq1's length is not known (gpu_run_program gets a ProgramData, not lengths):
+// the copy stops at the first NUL inside `limit1` bytes and the kernel learns the length from the final publication.
+// *n_out = Seq1's length (== limit1 when find_nul met no NUL).  The caller has checked m >= 1.
+// Measured, 1M x 10k on one MI355X (tools/stream_ab.sh, same box): psa_set_sequences 55.4 -> 44.4 us, gpu_run_program
+// 138.5 -> 122.2 us; chunks of 16 KB / 256 KB / 1 MB: 54 / 48 / 53 us; non-temporal stores for the copy: no gain (the
+// copy itself takes twice as long).  The kernel's last workgroup finishes ~31 us after the first started, against the
+// 25 us the PCIe reads alone take (tools/stream_phase.py).
+constexpr size_t kStreamChunk = 64 * 1024;
+constexpr size_t kStreamMin = 256 * 1024;        // shorter transfers: nothing to hide a poll over PCIe behind
+size_t stream_min()
+{
+#ifdef PSA_EXPERIMENT
+    // experiment knob (debug library): another threshold, e.g. a huge one to time the plain transfer on the same GPU
+    static const size_t v = std::getenv("PSA_STREAM_MIN") ? (size_t)std::atoll(std::getenv("PSA_STREAM_MIN")) : kStreamMin;
+    return v;
+#else
+    return kStreamMin;
+#endif
+}
+
+void stream_publish(psa_context* c, unsigned ticket, size_t bytes, bool final)
+{
+    __builtin_ia32_sfence();                      // (a libc memcpy may use non-temporal stores, which nothing else orders)
+    __atomic_store_n(c->h_ctl, ((unsigned long long)ticket << 40) | (final ? psa::kStreamFinal : 0ull) |
+                                   ((unsigned long long)bytes & psa::kStreamBytes), __ATOMIC_RELEASE);
+}
+
+struct StreamKnobs { size_t chunk; bool trace; };   // experiment knobs of the debug library
+const StreamKnobs& stream_knobs()
+{
+#ifdef PSA_EXPERIMENT
+    static const StreamKnobs k = {std::getenv("PSA_STREAM_CHUNK") ? (size_t)std::atoll(std::getenv("PSA_STREAM_CHUNK")) : kStreamChunk,
+                                  std::getenv("PSA_STREAM_TRACE") != nullptr};
+#else
+    static const StreamKnobs k = {kStreamChunk, false};
+#endif
+    return k;
+}
+
+psa_status stream_pair(psa_context* c, const char* seq1, size_t limit1, bool find_nul, const char* seq2, size_t m, int* n_out)
+{
+    SearchSlot& s = c->slot[0];
+    const auto t_enter = std::chrono::steady_clock::now();
+    if (!c->h_ctl) {
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ctl), 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *c->h_ctl = 0ull;
+        PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->hd_ctl), c->h_ctl, 0));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_ctl), 64));
+        PSA_HIP(hipMemsetAsync(c->d_ctl, 0, 64, c->stream));
+    }
+    const size_t second = ((limit1 + 63) & ~(size_t)63) + 64;
+    PSA_TRY(ensure_stage(c, second + m));
+    c->stage_second = second;
+    c->stream_ticket = (c->stream_ticket + 1) & 0xffffffu;
+    if (c->stream_ticket == 0) c->stream_ticket = 1;
+    const unsigned ticket = c->stream_ticket;
+    std::memcpy(c->h_stage + second, seq2, m);
+    if (!c->stream_force_timeout) stream_publish(c, ticket, 0, false);
+
+    psa::PrepareArgs a1;
+    psa::Seq2Args a2;
+    FilterPlan p;
+    PSA_TRY(seq1_args(c, c->hd_stage, (int)limit1, &a1));        // (room for the longest Seq1 the caller may hold)
+    PSA_TRY(seq2_args(s, c->hd_stage + second, (int)m, (int)limit1, c->d_bad, &a2, &p));
+    const int blocks1 = (c->nslots + 255) / 256, blocks2 = (s.m_cap / 16 + 255) / 256;
+    hipLaunchKernelGGL(psa::psa_encode_pair_streamed_kernel, dim3(1 + blocks1 + blocks2), dim3(256), 0, c->stream, a1, a2, blocks1,
+                       c->hd_ctl, c->d_ctl, ticket, c->stream_force_timeout ? 0 : (1 << 16));   // 2^16 polls of ~2 us
+    const hipError_t launched = hipGetLastError();
+    // (whatever happens from here on, the kernel is told that nothing more will come)
+    size_t done = 0;
+    bool end = !find_nul && limit1 == 0;
+    const StreamKnobs& knobs = stream_knobs();
+    const auto t_launched = std::chrono::steady_clock::now();
+    while (!end && launched == hipSuccess) {
+        size_t k = std::min(knobs.chunk, limit1 - done);
+        if (find_nul) {
+            const void* z = std::memchr(seq1 + done, 0, k);
+            if (z) { k = (size_t)(static_cast<const char*>(z) - (seq1 + done)); end = true; }
+        }
+        std::memcpy(c->h_stage + done, seq1 + done, k);
+        done += k;
+        if (done == limit1) end = true;
+        if (!end && !c->stream_force_timeout) stream_publish(c, ticket, done, false);
+    }
+    if (!c->stream_force_timeout) stream_publish(c, ticket, done, true);
+    if (knobs.trace) {
+        const auto t_end = std::chrono::steady_clock::now();
+        (void)hipStreamSynchronize(c->stream);
+        const auto t_sync = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "stream_pair: launch %.1f us, copy %.1f us, kernel end %.1f us after the last publication\n",
+                     std::chrono::duration<double, std::micro>(t_launched - t_enter).count(),
+                     std::chrono::duration<double, std::micro>(t_end - t_launched).count(),
+                     std::chrono::duration<double, std::micro>(t_sync - t_end).count());
+    }
+    if (launched != hipSuccess) { set_last_error(std::string("encode launch: ") + hipGetErrorString(launched)); return PSA_ERR_DEVICE; }
+    *n_out = (int)done;
+    c->streamed += 1;
+    if (done >= 1) {
+        c->n = (int)done;
+        seq2_encoded(s, (int)m, p);
+    }
     return PSA_OK;
 }
 
@@ -1435,6 +1567,7 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     if (const char* r = std::getenv("PSA_DUO_QUERIES")) c->duo_queries = std::max(2, std::min(4096, std::atoi(r)));
     if (const char* r = std::getenv("PSA_DUO_SKEW")) c->duo_skew_ticks = std::max(0, std::atoi(r));
     if (const char* r = std::getenv("PSA_DUO_FORCE_TIMEOUT")) c->duo_force_timeout = std::atoi(r) != 0;
+    if (const char* r = std::getenv("PSA_STREAM_FORCE_TIMEOUT")) c->stream_force_timeout = std::atoi(r) != 0;
 #endif
     *out = c;
     return PSA_OK;
@@ -1476,6 +1609,8 @@ void psa_destroy(psa_context* c)
     for (auto& ev : c->pool_events) (void)hipEventDestroy(ev);
     if (c->h_tails) (void)hipHostFree(c->h_tails);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
+    (void)hipFree(c->d_ctl);
     if (c->h_bad) (void)hipHostFree(c->h_bad);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -1556,6 +1691,16 @@ psa_status psa_set_sequences(psa_context* c, const char* seq1, int n, const char
     if (!c || !seq1 || !seq2 || n < 1 || m < 1) { set_last_error("psa_set_sequences: bad arguments"); return PSA_ERR_ARG; }
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
+    if ((size_t)n >= stream_min()) {
+        // long sequences: the encode launch goes first and follows the host's copy chunk by chunk (stream_pair)
+        int got = 0;
+        c->stream_gave_up = false;
+        PSA_TRY(stream_pair(c, seq1, (size_t)n, false, seq2, (size_t)m, &got));
+        PSA_TRY(check_bad_now(c));
+        const psa_status st = report_bad(c);
+        if (!c->stream_gave_up) return st;
+        c->stream_gave_up = false;                  // (never expected: the host thread stalled for > 0.1 s mid-copy)
+    }
     PSA_TRY(stage_pinned_pair(c, seq1, (size_t)n, seq2, (size_t)m));
     PSA_TRY(encode_pair(c, c->hd_stage, n, c->hd_stage + c->stage_second, m));     // reads the host copy over PCIe
     PSA_TRY(check_bad_now(c));
@@ -2641,6 +2786,11 @@ static std::mutex g_legacy_mutex;
 static psa_context* g_legacy_ctx = nullptr;
 static psa_group*   g_legacy_group = nullptr;
 
+// Host-to-device transfers of this context (NULL: of the context behind gpu_run_program) that were streamed — the
+// encode launch following the host's copy chunk by chunk — and how many of those had to be redone the plain way.
+int psa_streamed_count(psa_context* c) { if (!c) c = g_legacy_ctx; return c ? c->streamed : 0; }
+int psa_stream_retry_count(psa_context* c) { if (!c) c = g_legacy_ctx; return c ? c->stream_retries : 0; }
+
 static void legacy_die(const char* what)
 {
     // cuda_funcs.cu:44-48 pattern: message on stderr, exit(EXIT_FAILURE)
@@ -2659,8 +2809,19 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
     std::memcpy(weights, base + 8, sizeof weights);
     const char* seq1 = base + 40;
     const char* seq2 = base + 40 + seq1_cap;
-    const int n = (int)strnlen(seq1, seq1_cap);
+    // A long Seq1 (no NUL in its first 256 KB) is not measured up front: its end is found while it is copied to the
+    // device (stream_pair), the encode launch already under way; n = -1 until then.
+    const size_t peek = std::min(seq1_cap, stream_min());
+    const void* nul = std::memchr(seq1, 0, peek);
+    bool stream = !nul && seq1_cap > peek;
+    int n = nul ? (int)(static_cast<const char*>(nul) - seq1) : (stream ? -1 : (int)seq1_cap);
     const int m = (int)strnlen(seq2, seq2_cap);
+    auto no_nul = [&]() {
+        std::fprintf(stderr, "gpu_run_program: no NUL inside seq1[%zu] / seq2[%zu] - the caller's ProgramData was compiled with "
+                             "other array limits than this entry point reads (the plain symbol reads the reference's stock "
+                             "10001 / 5001 layout; other limits: gpu_run_program_layout, or include psa.h)\n", seq1_cap, seq2_cap);
+        std::exit(EXIT_FAILURE);
+    };
 
     returned_mutant->offset = -1;          // cuda_funcs.cu:158-160
     returned_mutant->char_offset = -1;
@@ -2669,13 +2830,8 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
     // A plain symbol cannot see how its caller compiled ProgramData.  What a mismatch looks like from here: no NUL
     // inside an array, or an empty Seq2 (the caller's seq2 lies elsewhere).  Say so instead of answering from the
     // wrong bytes (the reference prints and exits on every error, cuda_funcs.cu:44-48).
-    if ((size_t)n >= seq1_cap || (size_t)m >= seq2_cap) {
-        std::fprintf(stderr, "gpu_run_program: no NUL inside seq1[%zu] / seq2[%zu] - the caller's ProgramData was compiled with "
-                             "other array limits than this entry point reads (the plain symbol reads the reference's stock "
-                             "10001 / 5001 layout; other limits: gpu_run_program_layout, or include psa.h)\n", seq1_cap, seq2_cap);
-        std::exit(EXIT_FAILURE);
-    }
-    if (m < 1 && n >= 1 && last_offset > first_offset) {
+    if ((!stream && (size_t)n >= seq1_cap) || (size_t)m >= seq2_cap) no_nul();
+    if (m < 1 && (stream || n >= 1) && last_offset > first_offset) {
         std::fprintf(stderr, "gpu_run_program: seq2 is empty at offset %zu of ProgramData - if the caller was compiled with array "
                              "limits other than %zu / %zu its seq2 lies elsewhere (use gpu_run_program_layout, or include psa.h); "
                              "nothing searched\n", (size_t)40 + seq1_cap, seq1_cap, seq2_cap);
@@ -2698,6 +2854,11 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
     }
     psa_result r;
     if (devices.size() > 1) {
+        if (stream) {                        // (the group's setters want the length)
+            stream = false;
+            n = (int)strnlen(seq1, seq1_cap);
+            if ((size_t)n >= seq1_cap) no_nul();
+        }
         if (n < 1) legacy_die("Failed to copy data from host to device (seq1)");
         // PSA_EXCHANGE=host: the records meet in host memory instead of an RCCL all-gather (a device may then be listed
         // more than once: an N-way split rehearsed on fewer GPUs)
@@ -2722,10 +2883,24 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
         // The two arrays of a ProgramData lie side by side: one host memcpy into pinned staging (the reference copies the
         // whole struct, cuda_funcs.cu:50), an encode launch that reads it over PCIe, one search launch; the alphabet flag
         // comes back with the result tail.
-        if (n < 1 || ensure_device(c) != PSA_OK || stage_pinned_pair(c, seq1, (size_t)n, seq2, (size_t)m) != PSA_OK ||
-            encode_pair(c, c->hd_stage, n, c->hd_stage + c->stage_second, m) != PSA_OK)
-            legacy_die("Failed to copy data from host to device");
-        if (psa_search(c, first_offset, last_offset, &r) != PSA_OK) legacy_die("Failed to run the search");
+        bool searched = false;
+        if (stream) {
+            // long sequences: the encode launch first, the host's copy (and its search for Seq1's end) under the PCIe
+            // transfer, the search launch behind it
+            c->stream_gave_up = false;
+            if (ensure_device(c) != PSA_OK || stream_pair(c, seq1, seq1_cap, true, seq2, (size_t)m, &n) != PSA_OK)
+                legacy_die("Failed to copy data from host to device");
+            if ((size_t)n >= seq1_cap) no_nul();
+            searched = psa_search(c, first_offset, last_offset, &r) == PSA_OK;
+            if (!searched && !c->stream_gave_up) legacy_die("Failed to run the search");
+            c->stream_gave_up = false;       // (gave up: the host stalled mid-copy; once more the plain way)
+        }
+        if (!searched) {
+            if (n < 1 || ensure_device(c) != PSA_OK || stage_pinned_pair(c, seq1, (size_t)n, seq2, (size_t)m) != PSA_OK ||
+                encode_pair(c, c->hd_stage, n, c->hd_stage + c->stage_second, m) != PSA_OK)
+                legacy_die("Failed to copy data from host to device");
+            if (psa_search(c, first_offset, last_offset, &r) != PSA_OK) legacy_die("Failed to run the search");
+        }
     }
     if (r.offset < 0 || r.ch == 0) return none;   // cuda_funcs.cu:143-144
     returned_mutant->offset = r.offset;

@@ -299,6 +299,105 @@ __global__ __launch_bounds__(256) void psa_encode_pair_kernel(PrepareArgs a1, Se
     else encode_seq2_16(a2, (((int)blockIdx.x - blocks1) * 256 + threadIdx.x) * 16);
 }
 
+// ---- the same launch FOLLOWING the host's copy (psa_set_sequences, gpu_run_program on long sequences) -------------
+// The sequences lie in pageable host memory; the host copies them into pinned, host-coherent staging in chunks and this
+// kernel — launched BEFORE the copy starts — reads every chunk over PCIe as soon as the host has published it, so the
+// launch latency and the host's copy run under the PCIe transfer instead of in front of it.  One 64-bit control word
+// in the same pinned memory: ticket (bits 40-63: this launch's number), final (bit 39: Seq1's end is known and
+// everything has been copied; the byte count is then Seq1's length — the caller of gpu_run_program does not pass it,
+// the host finds the NUL while it copies), bytes (bits 0-38: bytes of Seq1 copied so far).  Seq2 is copied before the
+// first publication.
+// Workgroup 0 is the POLLER: one lane reads the host's word over PCIe and forwards every new value to a word in device
+// memory, which the other workgroups watch.  (Every workgroup polling the host's word itself was measured: 130 reads of
+// one cache line that the copying core keeps modified are answered one snoop at a time — the first workgroup was let go
+// 11 us after its chunk had been published, the last 52 us after the launch.)  Nobody waits for anything but the host
+// and the poller, which is dispatched first; the poller gives up after `spin_limit` polls (bad |= 8, "nothing arrived":
+// the host redoes the transfer the plain way), the watchers after four times as many.
+constexpr unsigned long long kStreamFinal = 1ull << 39;
+constexpr unsigned long long kStreamBytes = kStreamFinal - 1;
+constexpr int kStreamBad = 8;
+
+__device__ __forceinline__ void stream_poller(const unsigned long long* host_word, unsigned long long* dev_word,
+                                              unsigned ticket, int spin_limit, int* bad)
+{
+    if (threadIdx.x != 0) return;
+    unsigned long long last = 0ull;
+    for (int spins = 0;; ++spins) {
+        const unsigned long long w = __hip_atomic_load(host_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(w >> 40) == ticket && w != last) {
+            __hip_atomic_store(dev_word, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            last = w;
+            if (w & kStreamFinal) return;
+        }
+        if (spins >= spin_limit) {
+            atomicOr(bad, kStreamBad);
+            __hip_atomic_store(dev_word, ((unsigned long long)ticket << 40) | kStreamFinal, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);           // "Seq1 is empty": every symbol is padding
+            return;
+        }
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+// the forwarded word once it belongs to this launch and says that `need_bytes` of Seq1 are there (or that all is)
+__device__ __forceinline__ unsigned long long stream_wait(const unsigned long long* dev_word, unsigned ticket,
+                                                          unsigned long long need_bytes, int spin_limit, int* bad)
+{
+    __shared__ unsigned long long s_word;
+    if (threadIdx.x == 0) {
+        unsigned long long w = 0ull;
+        for (long long spins = 0;; ++spins) {
+            w = __hip_atomic_load(dev_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(w >> 40) == ticket && ((w & kStreamFinal) != 0ull || (w & kStreamBytes) >= need_bytes)) break;
+            if (spins >= 4ll * spin_limit) {
+                atomicOr(bad, kStreamBad);
+                w = ((unsigned long long)ticket << 40) | kStreamFinal;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        s_word = w;
+    }
+    __syncthreads();
+    // No cache maintenance: the polls are relaxed loads and there is no acquire fence (a system-scope acquire invalidates
+    // the L2 — per poll and workgroup that was measured to double the kernel's time).  None is needed: the staging
+    // buffer is fine-grained host memory, which the GPU does not cache, and no lane of this launch has touched the bytes
+    // it is about to read; the loads below are issued after the poll that saw the publication has returned.
+    asm volatile("" ::: "memory");
+    return s_word;
+}
+
+__global__ __launch_bounds__(256) void psa_encode_pair_streamed_kernel(PrepareArgs a1, Seq2Args a2, int blocks1,
+                                                                       const unsigned long long* host_word,
+                                                                       unsigned long long* dev_word, unsigned ticket,
+                                                                       int spin_limit)
+{
+#ifdef PSA_PHASE_TIMING
+#define PSA_EPHASE(k) do { if (threadIdx.x == 0 && blockIdx.x < 1000) g_phase_ts[blockIdx.x][k] = wall_clock64(); } while (0)
+#else
+#define PSA_EPHASE(k) do { } while (0)
+#endif
+    PSA_EPHASE(0);
+    if (blockIdx.x == 0) {
+        stream_poller(host_word, dev_word, ticket, spin_limit, a1.bad);
+        PSA_EPHASE(1);
+        return;
+    }
+    const int block = (int)blockIdx.x - 1;
+    if (block < blocks1) {
+        const unsigned long long end = ((unsigned long long)block + 1ull) * 256ull * 32ull;       // bytes this block reads
+        const unsigned long long w = stream_wait(dev_word, ticket, end, spin_limit, a1.bad);
+        // not final: the host has copied `end` bytes without meeting Seq1's end, so all of this block's are symbols
+        a1.n = (w & kStreamFinal) ? (int)(w & kStreamBytes) : (int)end;
+        PSA_EPHASE(1);
+        prepare_seq1_slot(a1, block * 256 + threadIdx.x);
+        PSA_EPHASE(2);
+    } else {
+        (void)stream_wait(dev_word, ticket, 0ull, spin_limit, a2.bad);     // Seq2 is in place before the first publication
+        encode_seq2_16(a2, ((block - blocks1) * 256 + threadIdx.x) * 16);
+    }
+}
+
 // out[b] bit t = in[t] bit b  (recursive block swap, Hacker's Delight 7-3, mirrored)
 __device__ __forceinline__ void transpose32(unsigned (&a)[32])
 {

@@ -34,7 +34,7 @@ EXPORTED_SYMBOLS = (
     "psa_set_seq1", "psa_set_seq2", "psa_set_seq1_device", "psa_set_seq2_device",
     "psa_set_sequences", "psa_set_sequences_device",
     "psa_set_engine", "psa_set_batch_streams", "psa_search", "psa_search_async", "psa_search_wait", "psa_search_device",
-    "psa_raw_retry_count", "psa_scores",
+    "psa_raw_retry_count", "psa_scores", "psa_streamed_count", "psa_stream_retry_count",
     "psa_search_batch", "psa_search_batch_device",
     "psa_search_batch_minmax", "psa_search_batch_minmax_device",
     "psa_debug_counts", "psa_fallback_count", "psa_reselect_count", "psa_unfused_count", "psa_duo_retry_count", "psa_debug_rescore",
@@ -92,6 +92,8 @@ def _load() -> C.CDLL:
     lib.psa_search_async.argtypes = [vp, i, i]
     lib.psa_search_device.argtypes = [vp, vp, i, vp, i, i, i, C.POINTER(Result)]
     lib.psa_raw_retry_count.argtypes = [vp]
+    lib.psa_streamed_count.argtypes = [vp]
+    lib.psa_stream_retry_count.argtypes = [vp]
     lib.psa_search_wait.argtypes = [vp, C.POINTER(Result)]
     lib.psa_scores.argtypes = [vp, i, i, vp, vp, vp]
     lib.psa_search_batch.argtypes = [vp, C.c_char_p, i, i, C.c_size_t, i, i, C.POINTER(Result)]
@@ -300,6 +302,14 @@ class Context:
     def raw_retry_count(self) -> int:
         """One-shot searches the one launch did not settle (redone through set_sequences_device + search)."""
         return lib.psa_raw_retry_count(self._h)
+
+    def streamed_count(self) -> int:
+        """Host-to-device transfers of this context that were streamed (the encode launch follows the host's copy)."""
+        return lib.psa_streamed_count(self._h)
+
+    def stream_retry_count(self) -> int:
+        """... and how many of those were redone the plain way (the kernel gave up waiting for the host)."""
+        return lib.psa_stream_retry_count(self._h)
 
     def search_async(self, first: int, last: int):
         _check(lib.psa_search_async(self._h, first, last))

@@ -675,6 +675,111 @@ def test_set_sequences_equals_the_two_setters(psa):
         assert key(c.search()) == want
 
 
+def _program_data(w, is_max, s1, s2, cap1, cap2):
+    """A ProgramData with array limits cap1 / cap2 (program_data.h:6-13): is_max@0, weights@8, seq1@40, seq2@40+cap1."""
+    buf = bytearray(40 + cap1 + cap2)
+    buf[0:4] = int(is_max).to_bytes(4, "little")
+    buf[8:40] = np.array(w, np.float64).tobytes()
+    buf[40:40 + len(s1)] = s1
+    buf[40 + cap1:40 + cap1 + len(s2)] = s2
+    return buf
+
+
+def test_long_host_sequences_are_streamed(psa):
+    """Host sequences of 256 KB and more: the encode launch goes first and follows the host's copy chunk by chunk
+    (stream_pair).  Same answers as the device-resident path for lengths on and off the 64 KB chunk and 8 KB workgroup
+    boundaries, a bad character in the last chunk is still reported, shorter sequences keep the plain path."""
+    import torch
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch, r.pairs)
+    with psa.Context(0) as c:
+        c.set_weights(W_README, True)
+        for n, m in ((262_144, 1000), (262_145, 33), (300_000, 2131), (1_000_000, 10_000), (327_680 + 8192, 700)):
+            s1, s2 = psa.generate_sequence(71, n), psa.generate_sequence(72, m)
+            t1 = torch.frombuffer(bytearray(s1), dtype=torch.uint8).cuda()
+            t2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
+            torch.cuda.synchronize()
+            c.set_sequences_device(t1.data_ptr(), n, t2.data_ptr(), m)
+            want = key(c.search())
+            before = c.streamed_count()
+            c.set_sequences(s1, s2)
+            assert c.streamed_count() == before + 1 and c.stream_retry_count() == 0
+            assert key(c.search()) == want
+            assert key(c.search(n // 3, n // 2)) == key(c.search(n // 3, n // 2))
+            # a longer pair before, a shorter one after: nothing of the earlier transfer shines through
+            c.set_sequences(s1[: n - 5000], s2)
+            c.set_sequences_device(t1.data_ptr(), n - 5000, t2.data_ptr(), m)
+        s1, s2 = psa.generate_sequence(73, 400_000), psa.generate_sequence(74, 500)
+        for where in (0, 65_535, 65_536, 399_999):
+            bad = s1[:where] + b"a" + s1[where + 1:]
+            with pytest.raises(psa.PsaError) as e:
+                c.set_sequences(bad, s2)
+            assert e.value.status == psa.PSA_ERR_ALPHABET
+        with pytest.raises(psa.PsaError) as e:
+            c.set_sequences(s1, s2[:499] + b"?")
+        assert e.value.status == psa.PSA_ERR_ALPHABET
+        c.set_sequences(s1, s2)
+        want = key(c.search())
+        before = c.streamed_count()
+        c.set_sequences(s1[:100_000], s2)                       # below the threshold: the plain transfer
+        assert c.streamed_count() == before
+        c.set_seq1(s1)
+        c.set_seq2(s2)
+        assert key(c.search()) == want
+
+
+def test_legacy_entry_streams_a_long_program_data(psa):
+    """gpu_run_program on a ProgramData compiled with long limits: Seq1's end is found while it is copied (the kernel
+    learns the length from the final publication), for a Seq1 that fills its array, one that ends inside a chunk, one
+    whose NUL is the first byte of a chunk and a short one in a long array (plain path)."""
+    w = W_README
+    cap1, cap2 = 1_000_001, 10_001
+    m = psa.Mutant()
+    with psa.Context(0) as c:
+        c.set_weights(w, True)
+        for n, mm, streamed in ((1_000_000, 10_000, 1), (300_000, 2131, 1), (262_144 + 65_536, 1000, 1), (9711, 2131, 0)):
+            s1, s2 = psa.generate_sequence(81, n), psa.generate_sequence(82, mm)
+            c.set_seq1(s1)
+            c.set_seq2(s2)
+            buf = _program_data(w, True, s1, s2, cap1, cap2)
+            # (bytes behind the NUL are never looked at: a stale tail of an earlier, longer sequence)
+            buf[40 + n + 1:40 + cap1] = b"Z" * (cap1 - n - 1)
+            data = (C.c_char * len(buf)).from_buffer(buf)
+            for first, last in ((0, n - mm + 1), (n // 4, n // 2)):
+                want = c.search(first, last)
+                before = psa.lib.psa_streamed_count(None)
+                score = psa.lib.gpu_run_program_layout(C.addressof(data), cap1, cap2, C.byref(m), first, last)
+                assert psa.lib.psa_streamed_count(None) == before + streamed
+                assert (score, m.offset, m.char_offset, m.ch) == (want.score, want.offset, want.char_offset, bytes([want.ch]))
+        assert psa.lib.psa_stream_retry_count(None) == 0
+
+
+def test_streamed_transfer_that_gives_up_is_redone(psa_debug, monkeypatch):
+    """The streamed encode launch waits for nobody but the host and gives up after a spin limit; the debug library forces
+    that (the host publishes nothing, the kernel gives up at its first poll): the transfer is redone the plain way and
+    the answers are the same, through psa_set_sequences and through gpu_run_program."""
+    psa = psa_debug
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch, r.pairs)
+    n, mm = 300_000, 1500
+    s1, s2 = psa.generate_sequence(91, n), psa.generate_sequence(92, mm)
+    with psa.Context(0) as c:
+        c.set_weights(W_README, False)
+        c.set_seq1(s1)
+        c.set_seq2(s2)
+        want = c.search()
+    monkeypatch.setenv("PSA_STREAM_FORCE_TIMEOUT", "1")
+    with psa.Context(0) as c:
+        c.set_weights(W_README, False)
+        c.set_sequences(s1, s2)
+        assert (c.streamed_count(), c.stream_retry_count()) == (1, 1)
+        assert key(c.search()) == key(want)
+    buf = _program_data(W_README, False, s1, s2, 1_000_001, 10_001)
+    data = (C.c_char * len(buf)).from_buffer(buf)
+    mut = psa.Mutant()
+    score = psa.lib.gpu_run_program_layout(C.addressof(data), 1_000_001, 10_001, C.byref(mut), 0, n - mm + 1)
+    assert (score, mut.offset, mut.char_offset, mut.ch) == (want.score, want.offset, want.char_offset, bytes([want.ch]))
+    assert psa.lib.psa_stream_retry_count(None) == 1
+
+
 def test_drop_in_program_with_psa_devices(psa, tmp_path):
     """PSA_DEVICES routes the drop-in binary through the device group (here: a group of one)."""
     import shutil

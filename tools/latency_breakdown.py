@@ -84,6 +84,8 @@ print(f"sequences already set, search only                     : {med(ctx.search
 print(f"host inputs, set_seq1 + set_seq2 + search              : {med(host_two):7.1f} us")
 print(f"host inputs, set_sequences + search                    : {med(host_pair):7.1f} us")
 print(f"gpu_run_program (ProgramData in host memory)           : {med(legacy):7.1f} us")
+print(f"host transfers streamed (encode launch follows the copy): context {ctx.streamed_count()} (redone {ctx.stream_retry_count()}), "
+      f"gpu_run_program {psa.lib.psa_streamed_count(None)} (redone {psa.lib.psa_stream_retry_count(None)})")
 ctx.set_profiling(True)
 for _ in range(10):
     ctx.search()
