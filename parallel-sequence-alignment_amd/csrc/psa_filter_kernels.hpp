@@ -939,9 +939,19 @@ __device__ __forceinline__ void classify_chars(const unsigned char* __restrict__
     }
 }
 
+// s + v(lane 0) + v(lane 1) + ... + v(lane 63), added in that order (cpu_funcs.c:278): every lane's addend reaches the
+// adder as a scalar operand (v_readlane), so the chain is 64 dependent v_add_f64 and nothing else — read back from LDS
+// as broadcast ds_read_b128 the adds waited for the LDS every other step (1.24 us per 64 chars instead of ~0.4).
+__device__ __forceinline__ double chain64(double s, double mine)
+{
+    const long long bits = __double_as_longlong(mine);
+#pragma unroll
+    for (int l = 0; l < 64; ++l) s += __longlong_as_double(readlane64(bits, l));
+    return s;
+}
+
 struct WalkScratch {                // per walking wave, in LDS
-    double    vals[64];
-    long long round[8];
+    long long round[8];             // the integer walk's R_e[class]
 };
 struct WalkStats { int chain, batches, left; };     // how a walk went (phase-timing builds print them)
 
@@ -981,16 +991,7 @@ __device__ __forceinline__ double walk_sum(double s, const unsigned char* s_code
             ++st.chain;
             // plain chain over the next <= 64 chars; lanes past the chunk hold +0.0 (exact to add)
             const int nb = c1 - k < 64 ? c1 - k : 64;
-            ws->vals[lane] = lane < nb ? s_class[s_codes[k - c0 + lane] & 7u] : 0.0;
-            __builtin_amdgcn_wave_barrier();
-            const double2* v = reinterpret_cast<const double2*>(ws->vals);   // same address in every lane: broadcast
-#pragma unroll
-            for (int l = 0; l < 32; ++l) {
-                const double2 x = v[l];
-                s += x.x;                                 // reference order (cpu_funcs.c:278)
-                s += x.y;
-            }
-            __builtin_amdgcn_wave_barrier();
+            s = chain64(s, lane < nb ? s_class[s_codes[k - c0 + lane] & 7u] : 0.0);   // reference order (cpu_funcs.c:278)
             k += nb;
             continue;
         }
@@ -1316,19 +1317,8 @@ __device__ __forceinline__ bool certified_sum(const unsigned char* s_codes, int 
     PSA_SPHASE(1);
     // ---- the first chars: plain chain (cpu_funcs.c:278), lanes past the end hold +0.0
     const int head = m < kCertChain ? m : kCertChain;
-    ws->vals[lane] = lane < head ? s_class[s_codes[lane] & 7u] : 0.0;
-    __builtin_amdgcn_wave_barrier();
-    double s = 0.0;
-    {
-        const double2* v = reinterpret_cast<const double2*>(ws->vals);
-#pragma unroll
-        for (int l = 0; l < 32; ++l) {
-            const double2 x = v[l];
-            s += x.x;
-            s += x.y;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
+    double s = chain64(0.0, lane < head ? s_class[s_codes[lane] & 7u] : 0.0);
+    (void)ws;
     PSA_SPHASE(2);
     // ---- events: event i = the interior run behind the previous true addition (or the head) + true addition i;
     // the last event (i == ntrue) is the run up to m alone.  One lane per event prepares it, then the wave applies
@@ -1389,16 +1379,29 @@ __device__ __forceinline__ bool certified_sum(const unsigned char* s_codes, int 
         // lane reads of the second do not wait for the first one's arithmetic.
         const int count = ntrue + 1 - i0 < 64 ? ntrue + 1 - i0 : 64;
         const long long sdelta = (key & 0x800u) ? -(long long)delta : (long long)delta;
-        bool ok = true;
+        // The state lives in two VECTOR registers the compiler cannot prove uniform (the empty asm): every step of an
+        // event is then a VALU instruction fed by the event's scalars (v_readlane) — and-or, 64-bit add, and-or,
+        // v_add_f64, ~40 cycles of dependent issue.  Left to itself the compiler keeps the (uniform) state in scalar
+        // registers and crosses between the scalar and the vector unit four times per event (270 cycles each).
+        unsigned s_lo = (unsigned)(unsigned long long)__double_as_longlong(s);
+        unsigned s_hi = (unsigned)((unsigned long long)__double_as_longlong(s) >> 32);
+        unsigned bad_acc = 0u;
+        asm volatile("" : "+v"(s_lo), "+v"(s_hi));
         auto apply = [&](int j) {
             const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
-            const long long dj = readlane64(sdelta, j);
+            const unsigned long long dj = (unsigned long long)readlane64(sdelta, j);
             const double vj = __longlong_as_double(readlane64(__double_as_longlong(v), j));
-            const unsigned long long sb = (unsigned long long)__double_as_longlong(s);
-            const long long S = (long long)((sb & 0xfffffffffffffull) | (1ull << 52)) + dj;    // |sum| in ulps of its binade
-            // the state is in the certified binade and the run stays strictly inside it (the certificate says both)
-            ok &= ((kj & 0x1000u) == 0u) | (((unsigned)(sb >> 52) == (kj & 0xfffu)) & (S > (1ll << 52)) & (S < (1ll << 53)));
-            s = __longlong_as_double((long long)((sb & 0xfff0000000000000ull) | ((unsigned long long)S & 0xfffffffffffffull))) + vj;
+            // |sum| in ulps of its binade, plus the run's integer
+            const unsigned long long S = ((((unsigned long long)((s_hi & 0xfffffu) | 0x100000u)) << 32) | s_lo) + dj;
+            // the state is in the certified binade and the run stays strictly inside it (the certificate says both):
+            // 2^52 < S < 2^53  <=>  S - 2^52 - 1 < 2^52 - 1 (unsigned)
+            const bool stays = (S - ((1ull << 52) + 1ull)) < ((1ull << 52) - 1ull);
+            const bool fine = ((kj & 0x1000u) == 0u) | (((s_hi >> 20) == (kj & 0xfffu)) & stays);
+            bad_acc |= fine ? 0u : 1u;
+            const unsigned n_hi = (s_hi & 0xfff00000u) | ((unsigned)(S >> 32) & 0xfffffu);
+            const double x = __longlong_as_double((long long)(((unsigned long long)n_hi << 32) | (unsigned)S)) + vj;
+            s_lo = (unsigned)(unsigned long long)__double_as_longlong(x);
+            s_hi = (unsigned)((unsigned long long)__double_as_longlong(x) >> 32);
         };
         int j = 0;
         for (; j + 2 <= count; j += 2) {
@@ -1406,7 +1409,8 @@ __device__ __forceinline__ bool certified_sum(const unsigned char* s_codes, int 
             apply(j + 1);
         }
         if (j < count) apply(j);
-        failed = !ok;
+        s = __longlong_as_double((long long)(((unsigned long long)s_hi << 32) | s_lo));
+        failed = __ballot(bad_acc != 0u) != 0ull;
     }
     PSA_SPHASE(4);
     if (failed) return false;
