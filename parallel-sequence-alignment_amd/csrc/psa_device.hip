@@ -393,10 +393,15 @@ struct psa_context {
     bool granted16_raw = false;
     // Shares of a SIMD's four waves in the single-search count kernel, by age (oldest first), in permille.  The hardware
     // issues the oldest wave of a SIMD first: with equal shares it finished 25 us before the youngest and the SIMD ended on
-    // one wave that cannot fill its issue slots.  Measured, 1M x 10k, kernel us (whole classes): 2/2/2/2 87.8, 3/2/2/1
-    // 81.3, 2/3/2/1 84.5, 3/3/1/1 86.4, 3/3/2/0 86.0, 1/2/2/3 99.0; in rounds of 32 chars around 3/2/2/1 (same box):
-    // 375/250/250/125 89.3, 340/270/250/140 87.6, 330/280/240/150 87.8, 350/260/240/150 88.0, 400/250/225/125 91.6
-    int  single_deal[4] = {340, 270, 250, 140};
+    // one wave that cannot fill its issue slots.  Round 3, first form (every wave converted its own counts, the older ones
+    // early, under the younger waves' loops), kernel us at 1M x 10k: 2/2/2/2 classes 87.8, 3/2/2/1 81.3, 2/3/2/1 84.5,
+    // 3/3/1/1 86.4, 3/3/2/0 86.0, 1/2/2/3 99.0; in rounds of 32 chars 340/270/250/140 another 1.7 us.  Since the waves'
+    // counters are summed as bit planes behind a barrier (sum_dump / sum_take / sum_columns) nobody has conversion work to
+    // hide and the optimum is flat: same box, warm, kernel us: 350/270/240/140 76.8-77.3, 360/260/240/140 77.2,
+    // 320/270/250/160 77.3-77.5, 330/270/250/150 77.4, 340/270/250/140 77.8-78.3, 330/280/240/150 78.8-79.4,
+    // 310/280/260/150 79.1; another box: 300/270/250/180 81.0 and 250/250/250/250 83.9 against 78.2
+    // (tools/deal_sweep.py, gpurun_out/deal_sweep_r5l.txt, _r5j.txt).
+    int  single_deal[4] = {350, 270, 240, 140};
     // Batch kernel: share of a group's four older waves (the younger ones take the rest).  Its waves run with the younger
     // ones at the higher priority, so THEY finish first: measured per 256-query step 500 -> 15.27 ms, 375 -> 14.08 ms,
     // 250 -> 16.3 ms, 625 -> slower still; per 32-query launch 375 2.006 ms, 350 2.04, 400 2.07, 325 2.09, 425 2.10, 450 2.11

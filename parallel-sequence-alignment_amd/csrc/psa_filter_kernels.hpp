@@ -589,7 +589,16 @@ __device__ __forceinline__ WaveShare wave_share(int lo_round, int hi_round, int 
 constexpr int kTileWords = kTile / 32;
 constexpr int kCellDwords = kCounters * 16 * kTileWords;
 constexpr int kPlaneBytes = kMaskRows * kRowSlots * 8;          // the class-plane rows of a tile in LDS
-constexpr int kCountLdsBytes = kPlaneBytes + kCellDwords * 4;   // dynamic LDS of psa_count_kernel: planes + count cells
+// psa_count_kernel sums its 16 waves' counter planes BIT-SLICED before anything is converted (sum_dump / sum_take / sum_columns): the
+// exchange area, 8 slots of one wave's six 11-plane counters each, lies over the plane rows (dead by then) and a little
+// beyond them; the count cells follow it.
+constexpr int kXPairs = kPlanes / 2;                            // plane pairs of a (counter, word), one ds_*_b64 each
+constexpr int kXKwDwords = kXPairs * 128 + 64;                  // one (counter, word) of a wave: 5 pairs x 64 lanes x 2, plane 10 x 64 lanes
+constexpr int kXSlotDwords = 2 * kCounters * kXKwDwords;        // one wave: 4224 dwords
+constexpr int kXBytes = 8 * kXSlotDwords * 4;                   // 135,168
+static_assert(kPlanes == 10 && kXBytes >= kPlaneBytes, "exchange area: ten-plane counters, behind the plane rows' end");
+constexpr int kCellOffset = kXBytes;
+constexpr int kCountLdsBytes = kCellOffset + kCellDwords * 4;   // dynamic LDS of psa_count_kernel: 159,744 bytes
 
 // 16 plane words (planes 0..15 of 32 positions) -> 16 dwords, dword t = count(t) | count(t+16) << 16:
 // the lower four stages of the 32x32 bit-matrix transpose (Hacker's Delight 7-3), applied to both
@@ -631,6 +640,115 @@ __device__ __forceinline__ void add_counts_to_cells(Counter (&cnt)[2][kCounters]
                 __hip_atomic_fetch_add(cells + (k * 16 + t) * words + word, v[t], __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+    }
+}
+
+// ---- psa_count_kernel: the 16 waves' counters summed as bit planes, converted ONCE ------------------------------
+// add_counts_to_cells costs a wave ~1,050 instructions (six 16x16 bit transposes and 96 ds_adds): sixteen waves doing it
+// were 8.6 % of the kernel's instructions.  Adding two bit-sliced counters is one full adder per plane (20 instructions
+// per counter word), so the waves' planes are added first and only the totals are converted:
+//   1. waves 8-15 store their planes to the exchange area (sum_dump), barrier;
+//   2. wave w < 8 adds wave w + 8's planes to its own registers (sum_take: 11 planes) and stores the sum over what it
+//      has just read, barrier;
+//   3. 768 threads, one per (counter, word, lane, half): each adds four of the eight sums (13 planes), the halves meet
+//      through v_permlane32_swap (14 planes), the lower half converts its column (one 16x16 transpose) and stores the
+//      integer counts to the cells (plain stores: nothing else adds to them), barrier.
+// ~5,800 instructions per workgroup instead of 16,900.  The area lies over the plane rows, so step 1 starts behind a
+// barrier that every wave's main loop has passed.
+template <typename Counter>
+__device__ __forceinline__ void sum_dump(const Counter (&cnt)[2][kCounters], const unsigned (*top)[kCounters], unsigned* slot, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < kCounters; ++k)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            unsigned* at = slot + (k * 2 + w) * kXKwDwords;
+#pragma unroll
+            for (int pr = 0; pr < kXPairs; ++pr)
+                *reinterpret_cast<uint2*>(at + pr * 128 + lane * 2) = make_uint2(cnt[w][k].plane[2 * pr], cnt[w][k].plane[2 * pr + 1]);
+            if (top) at[kXPairs * 128 + lane] = top[w][k];
+        }
+}
+
+// cnt += the ten planes another wave stored in `slot`; the carry out of plane 9 goes to top (plane 10)
+template <typename Counter>
+__device__ __forceinline__ void sum_take(Counter (&cnt)[2][kCounters], unsigned (&top)[2][kCounters], const unsigned* slot, int lane)
+{
+#pragma unroll
+    for (int k = 0; k < kCounters; ++k)
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const unsigned* at = slot + (k * 2 + w) * kXKwDwords;
+            unsigned in[kPlanes];
+#pragma unroll
+            for (int pr = 0; pr < kXPairs; ++pr) {
+                const uint2 v = *reinterpret_cast<const uint2*>(at + pr * 128 + lane * 2);
+                in[2 * pr] = v.x;
+                in[2 * pr + 1] = v.y;
+            }
+            unsigned carry = 0u;
+#pragma unroll
+            for (int p = 0; p < kPlanes; ++p) carry = csa(cnt[w][k].plane[p], in[p], carry);
+            top[w][k] = carry;
+        }
+}
+
+// step 3 (threads 0..767 of the workgroup; X holds the eight 11-plane sums)
+__device__ __forceinline__ void sum_columns(const unsigned* X, unsigned* cells, int tid)
+{
+    const int lane = tid & 63, wv = tid >> 6;               // wv 0..11
+    const int half = lane >> 5;                             // which four of the eight sums
+    const int l = ((wv & 1) << 5) | (lane & 31);            // lane of the main loop = word l (w = 0) or 64 + l (w = 1)
+    const int kw = wv >> 1;                                 // counter k = kw >> 1, word half w = kw & 1
+    const unsigned* base = X + kw * kXKwDwords;
+    unsigned acc[14];
+    auto load = [&](int src, unsigned (&in)[11]) {
+        const unsigned* at = base + src * kXSlotDwords;
+#pragma unroll
+        for (int pr = 0; pr < kXPairs; ++pr) {
+            const uint2 v = *reinterpret_cast<const uint2*>(at + pr * 128 + l * 2);
+            in[2 * pr] = v.x;
+            in[2 * pr + 1] = v.y;
+        }
+        in[10] = at[kXPairs * 128 + l];
+    };
+    {
+        unsigned in[11];
+        load(4 * half, in);
+#pragma unroll
+        for (int p = 0; p < 11; ++p) acc[p] = in[p];
+        acc[11] = acc[12] = acc[13] = 0u;
+    }
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        unsigned in[11];
+        load(4 * half + q, in);
+        unsigned carry = 0u;
+#pragma unroll
+        for (int p = 0; p < 11; ++p) carry = csa(acc[p], in[p], carry);
+#pragma unroll
+        for (int p = 11; p < 13; ++p) {                     // half adders: four 11-bit numbers stay below 2^13
+            const unsigned t = acc[p] & carry;
+            acc[p] ^= carry;
+            carry = t;
+        }
+    }
+    // the other half's sum: lanes 0-31 receive what lanes 32-63 hold (v_permlane32_swap, gfx950)
+    unsigned carry = 0u;
+#pragma unroll
+    for (int p = 0; p < 13; ++p) {
+        const auto r = __builtin_amdgcn_permlane32_swap(acc[p], acc[p], false, false);
+        carry = csa(acc[p], (unsigned)r[1], carry);
+    }
+    acc[13] = carry;
+    if (half == 0) {
+        unsigned v[16];
+#pragma unroll
+        for (int p = 0; p < 16; ++p) v[p] = p < 14 ? acc[p] : 0u;
+        planes_to_counts(v);
+        unsigned* out = cells + (kw >> 1) * 16 * kTileWords + (kw & 1) * 64 + l;
+#pragma unroll
+        for (int t = 0; t < 16; ++t) out[t * kTileWords] = v[t];
     }
 }
 
@@ -1692,12 +1810,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     // bit matrices in registers — 14 KB of codes read per workgroup instead of 100 KB of planes.
     // RAW: the table is indexed by the ASCII byte ([2][256]); bit 31 of a lo entry marks a byte outside [A-Z-]
     __shared__ unsigned s_planes[RAW ? 512 : 64];
-    // The tile's count cells have LDS of their own behind the plane rows and start from zero, so a wave adds its counts
-    // the moment its main loop ends — the older waves of a SIMD finish 20 us before the youngest, and their
-    // transposes and ds_adds run under the others' main loops.
-    unsigned* const cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + kPlaneBytes);
+    // The tile's count cells lie behind the exchange area of the waves' counter sums (which covers the plane rows); they
+    // are written once, by sum_columns, with plain stores.
+    unsigned* const cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + kCellOffset);
     PSA_PHASE(0);
-    for (int i = tid; i < kCellDwords; i += WAVES * 64) cells[i] = 0u;
     {
         // the lower half of the workgroup transposes the lo planes, the upper half the hi planes;
         // a thread's first 32 codes are fetched together with the symbol table (one memory latency)
@@ -1777,7 +1893,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
             unsigned char* stage = reinterpret_cast<unsigned char*>(cells);
             const bool staged = a.m2 + (a.m2 >> 3) + 64 <= kCellDwords * 4;
             if (staged) {
-                __syncthreads();                                  // (the cells were being zeroed)
                 for (int i0 = tid * 16; i0 < a.m2; i0 += WAVES * 64 * 16) {
                     if (i0 != tid * 16) fetch2(i0);
                     bool any_bad = false;
@@ -1820,10 +1935,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
                 }
                 a.classes_w[j] = code << kRowShift;
             }
-            if (staged) {
-                __syncthreads();                                  // every staged code has been read: the cells again
-                for (int i = tid; i < kCellDwords; i += WAVES * 64) cells[i] = 0u;
-            }
         }
         const unsigned* tab = s_planes + (RAW ? 256 : 32) * hi_half;
         unsigned* dst = reinterpret_cast<unsigned*>(lds) + hi_half;
@@ -1858,12 +1969,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
 #pragma unroll
         for (int k = 0; k < kCounters; ++k) cnt[w][k].clear();
 
-    // this wave's shift classes: low_class .. low_class + kWaveClasses - 1, walked from the top down
-    // The hardware favours the oldest wave of a SIMD (waves w, w+4, w+8, w+12 share one), so with equal shares the oldest
-    // finishes 25 us before the youngest and the SIMD ends on one wave that cannot fill its issue slots.  `skew` (host:
-    // when three classes fit a wave's counters) deals 3 / 2 / 2 / 1 classes to the four ages instead of 2 / 2 / 2 / 2.
     // this wave's share of the chunk's symbol stream (host: deal_single — the hardware favours the oldest wave of a
-    // SIMD, so the shares differ by age)
+    // SIMD (waves w, w+4, w+8, w+12 share one), so the shares differ by age and all four finish together)
     const int class_chars_u = __builtin_amdgcn_readfirstlane(a.class_chars);
     const WaveShare share = wave_share(__builtin_amdgcn_readfirstlane((int)a.wave_lo[wave]),
                                        __builtin_amdgcn_readfirstlane((int)a.wave_hi[wave]), class_chars_u);
@@ -1882,13 +1989,25 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     const unsigned lane_base = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)lds + (unsigned)lane * 8u;
     count_stream(cnt, sym, share.first_k, share.chars, class_chars, share.low_class, lane_base, lane, row_of);
 
-    // ---- epilogue: every wave turns its counter planes into integers (bit-matrix transpose in
-    // registers, two 16-bit counts per dword) and adds them to the tile's cells in LDS (ds_add_u32);
+    // ---- epilogue: the waves' counter planes are summed bit-sliced (sum_dump / sum_take / sum_columns), the totals turned
+    // into integers (bit-matrix transpose in registers, two 16-bit counts per dword) and stored to the tile's cells;
     // each thread then picks up the counts of its offsets.
     PSA_PHASE(2);
-    add_counts_to_cells(cnt, cells, kTileWords, lane, true);
-    PSA_PHASE(3);
-    PSA_PHASE(4);
+    {
+        unsigned* const X = reinterpret_cast<unsigned*>(lds);
+        __syncthreads();                                  // every wave's main loop has ended: the plane rows are dead
+        if (wave >= 8) sum_dump(cnt, nullptr, X + (wave - 8) * kXSlotDwords, lane);
+        __syncthreads();
+        PSA_PHASE(3);
+        if (wave < 8) {
+            unsigned top[2][kCounters];
+            sum_take(cnt, top, X + wave * kXSlotDwords, lane);
+            sum_dump(cnt, top, X + wave * kXSlotDwords, lane);   // over what this wave has just read (a wave's LDS
+        }                                                        // operations execute in order)
+        __syncthreads();
+        PSA_PHASE(4);
+        if (tid < 768) sum_columns(X, cells, tid);
+    }
     __syncthreads();
 
     // each thread handles kTile / (WAVES*64) consecutive offsets of one word
