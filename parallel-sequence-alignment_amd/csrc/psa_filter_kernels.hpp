@@ -1992,7 +1992,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     // ---- epilogue: the waves' counter planes are summed bit-sliced (sum_dump / sum_take / sum_columns), the totals turned
     // into integers (bit-matrix transpose in registers, two 16-bit counts per dword) and stored to the tile's cells;
     // each thread then picks up the counts of its offsets.
-    PSA_PHASE(2);
+#ifdef PSA_PHASE_TIMING
+    // (when the workgroup's LAST wave left its main loop; zeroed by the host between searches it is not: the maximum
+    // of 100 MHz timestamps only grows)
+    if (lane == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1000) atomicMax(&g_phase_ts[blockIdx.y * gridDim.x + blockIdx.x][2], wall_clock64());
+#endif
     {
         unsigned* const X = reinterpret_cast<unsigned*>(lds);
         __syncthreads();                                  // every wave's main loop has ended: the plane rows are dead

@@ -36,15 +36,16 @@ buf = (C.c_ulonglong * (1024 * 8))()
 lib.psa_debug_phase_ts.restype = C.c_int
 assert lib.psa_debug_phase_ts(buf) == 0
 ts = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
-nt = 1024
+nt = 1000          # rows 1000.. hold the tail's and the re-score kernel's stamps
 ts = ts[:nt]
 ts = ts[ts[:, 0] > 0]
 t0 = ts[:, 0].min()
-names = ["build planes", "main loop (wave 0)", "barrier wait", "merge tree", "publish+expand", "bounds+select"]
+names = ["build planes", "main loop (to the LAST wave's end)", "barrier, waves 8-15 store planes, barrier", "waves 0-7 add + store, barrier",
+         "column sums, conversion, counts read", "bounds+select"]
 print(f"{len(ts)} workgroups; start spread {(ts[:,0].max()-t0)/100:.2f} us; last end {(ts[:,6].max()-t0)/100:.2f} us")
 for k, name in enumerate(names):
     d = (ts[:, k + 1] - ts[:, k]) / 100.0
-    print(f"{name:22s} mean {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
+    print(f"{name:44s} mean {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
 print("result", r)
 tail = ts[ts[:, 7] > 0]
 for row in tail:     # the workgroup that finished the search (finish_search)
