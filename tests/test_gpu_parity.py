@@ -352,6 +352,26 @@ def test_filter_class_counts_exact(psa, n, m, first, last):
             assert np.array_equal(got[k].astype(np.int64), want[k]), (n, m, k)
 
 
+def test_filter_class_counts_saturated(psa):
+    """The count kernel sums its 16 waves' counters as bit planes (10 -> 11 -> 13 -> 14 planes) before it converts them:
+    inputs in which EVERY pair of an offset falls in one class drive those sums to their maxima — the largest Seq2 one
+    workgroup takes in one chunk (11,264 chars: 992 per wave at most, 15,872 = 2^14 - 512 the bound of the 14 planes),
+    its neighbours, and a several-chunk plan.  '*' (n_lo), ':' (n_hi: N under D, both in NDEQ) and '.' (both planes:
+    S under G, SAG only) each saturate their own counter."""
+    for m in (11_264, 11_263, 10_000, 992, 13_000):
+        n = m + 9000
+        for a, b, which in ((b"A", b"A", 0), (b"N", b"D", 1), (b"S", b"G", 2)):
+            with psa.Context(0) as c:
+                c.set_engine(psa.ENGINE_FILTER)
+                c.set_weights(W_README, True)
+                c.set_seq1(a * n)
+                c.set_seq2(b * m)
+                got = c.debug_counts(0, n - m + 1)
+            for k in range(3):
+                want = m if k == which else 0
+                assert int(got[k].min()) == want and int(got[k].max()) == want, (m, a, b, k)
+
+
 @pytest.mark.parametrize("rec", DISTINCT_RECORDS)
 def test_filter_engine_reference_records(psa, oracle, reference_records, rec):
     w, s1, s2, is_max = reference_records[rec]
