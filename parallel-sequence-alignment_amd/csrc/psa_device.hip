@@ -804,16 +804,40 @@ const StreamKnobs& stream_knobs()
     return k;
 }
 
+// The streamed launch's last workgroup writes ticket << 40 | alphabet flag to the pinned "done" word: watching it
+// returns a few microseconds before a copy of the flag + the stream's completion signal would (a stalled launch falls
+// back to exactly that).
+psa_status stream_wait_done(psa_context* c)
+{
+    const volatile unsigned long long* done = c->h_ctl + 8;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int k = 0; k < 256; ++k) {
+            const unsigned long long w = *done;
+            if ((unsigned)(w >> 40) == c->stream_ticket) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                *c->h_bad = (int)(w & 0xffffffu);
+                return PSA_OK;
+            }
+            __builtin_ia32_pause();
+        }
+        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 2000.0) break;
+    }
+    return check_bad_now(c);
+}
+
 psa_status stream_pair(psa_context* c, const char* seq1, size_t limit1, bool find_nul, const char* seq2, size_t m, int* n_out)
 {
     SearchSlot& s = c->slot[0];
     const auto t_enter = std::chrono::steady_clock::now();
     if (!c->h_ctl) {
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ctl), 64, hipHostMallocMapped | hipHostMallocCoherent));
-        *c->h_ctl = 0ull;
+        // pinned: word 0 = the host's progress, word 8 (a cache line of its own) = the launch's "done" word;
+        // device: word 0 = the poller's copy of the progress, word 8 = the workgroups' arrival counter
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ctl), 128, hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(c->h_ctl, 0, 128);
         PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->hd_ctl), c->h_ctl, 0));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_ctl), 64));
-        PSA_HIP(hipMemsetAsync(c->d_ctl, 0, 64, c->stream));
+        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_ctl), 128));
+        PSA_HIP(hipMemsetAsync(c->d_ctl, 0, 128, c->stream));
     }
     const size_t second = ((limit1 + 63) & ~(size_t)63) + 64;
     PSA_TRY(ensure_stage(c, second + m));
@@ -831,7 +855,8 @@ psa_status stream_pair(psa_context* c, const char* seq1, size_t limit1, bool fin
     PSA_TRY(seq2_args(s, c->hd_stage + second, (int)m, (int)limit1, c->d_bad, &a2, &p));
     const int blocks1 = (c->nslots + 255) / 256, blocks2 = (s.m_cap / 16 + 255) / 256;
     hipLaunchKernelGGL(psa::psa_encode_pair_streamed_kernel, dim3(1 + blocks1 + blocks2), dim3(256), 0, c->stream, a1, a2, blocks1,
-                       c->hd_ctl, c->d_ctl, ticket, c->stream_force_timeout ? 0 : (1 << 16));   // 2^16 polls of ~2 us
+                       c->hd_ctl, c->d_ctl, ticket, c->stream_force_timeout ? 0 : (1 << 16),   // 2^16 polls of ~2 us
+                       reinterpret_cast<unsigned*>(c->d_ctl + 8), c->hd_ctl + 8);
     const hipError_t launched = hipGetLastError();
     // (whatever happens from here on, the kernel is told that nothing more will come)
     size_t done = 0;
@@ -1701,7 +1726,7 @@ psa_status psa_set_sequences(psa_context* c, const char* seq1, int n, const char
         int got = 0;
         c->stream_gave_up = false;
         PSA_TRY(stream_pair(c, seq1, (size_t)n, false, seq2, (size_t)m, &got));
-        PSA_TRY(check_bad_now(c));
+        PSA_TRY(stream_wait_done(c));
         const psa_status st = report_bad(c);
         if (!c->stream_gave_up) return st;
         c->stream_gave_up = false;                  // (never expected: the host thread stalled for > 0.1 s mid-copy)

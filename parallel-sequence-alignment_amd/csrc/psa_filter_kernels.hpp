@@ -367,10 +367,14 @@ __device__ __forceinline__ unsigned long long stream_wait(const unsigned long lo
     return s_word;
 }
 
+// `arrivals` (device, zero between launches) counts the workgroups that have finished; the last one hands the alphabet
+// flag to the host in `host_done` (pinned: ticket << 40 | flag), which psa_set_sequences polls instead of copying the
+// flag back and waiting for the stream (a copy command, its completion signal and the runtime's wake-up: ~8 us).
 __global__ __launch_bounds__(256) void psa_encode_pair_streamed_kernel(PrepareArgs a1, Seq2Args a2, int blocks1,
                                                                        const unsigned long long* host_word,
                                                                        unsigned long long* dev_word, unsigned ticket,
-                                                                       int spin_limit)
+                                                                       int spin_limit, unsigned* arrivals,
+                                                                       unsigned long long* host_done)
 {
 #ifdef PSA_PHASE_TIMING
 #define PSA_EPHASE(k) do { if (threadIdx.x == 0 && blockIdx.x < 1000) g_phase_ts[blockIdx.x][k] = wall_clock64(); } while (0)
@@ -378,13 +382,11 @@ __global__ __launch_bounds__(256) void psa_encode_pair_streamed_kernel(PrepareAr
 #define PSA_EPHASE(k) do { } while (0)
 #endif
     PSA_EPHASE(0);
+    const int block = (int)blockIdx.x - 1;
     if (blockIdx.x == 0) {
         stream_poller(host_word, dev_word, ticket, spin_limit, a1.bad);
         PSA_EPHASE(1);
-        return;
-    }
-    const int block = (int)blockIdx.x - 1;
-    if (block < blocks1) {
+    } else if (block < blocks1) {
         const unsigned long long end = ((unsigned long long)block + 1ull) * 256ull * 32ull;       // bytes this block reads
         const unsigned long long w = stream_wait(dev_word, ticket, end, spin_limit, a1.bad);
         // not final: the host has copied `end` bytes without meeting Seq1's end, so all of this block's are symbols
@@ -395,6 +397,17 @@ __global__ __launch_bounds__(256) void psa_encode_pair_streamed_kernel(PrepareAr
     } else {
         (void)stream_wait(dev_word, ticket, 0ull, spin_limit, a2.bad);     // Seq2 is in place before the first publication
         encode_seq2_16(a2, ((block - blocks1) * 256 + threadIdx.x) * 16);
+    }
+    // every wave's stores and flag updates have been performed, then ONE lane's arrival
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned arrived = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x - 1) {
+            __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned flag = (unsigned)__hip_atomic_load(a1.bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(host_done, ((unsigned long long)ticket << 40) | flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
