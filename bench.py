@@ -598,6 +598,33 @@ def main():
                                "10 searches of the probe needed (tests/test_gpu_parity.py checks the answers against the oracle)")
         ctx.set_weights(WEIGHTS, True)
 
+    # ---- SURVEY.md 8(d)'s other timed region: process start -> output.txt closed, the drop-in program on configs[2]
+    drop_in = None
+    exe = os.path.join(PKG, "host", "psa_main")
+    if extras and (n, m) == (1_000_000, 10_000) and os.path.exists(exe):
+        import tempfile
+        with tempfile.TemporaryDirectory() as tmp:
+            with open(os.path.join(tmp, "input.txt"), "wb") as f:           # cpu_funcs.c:358-365: weights, seq1, seq2, mode
+                f.write(b"1.5 2.6 0.3 0.2\n" + h1 + b"\n" + h2 + b"\nmaximum\n")
+            walls, inner, ok = [], [], True
+            env = dict(os.environ, PSA_DEVICE=str(local_rank))
+            for _ in range(3):
+                t0 = time.perf_counter()
+                p = subprocess.run([exe], cwd=tmp, env=env, capture_output=True, text=True)
+                walls.append(time.perf_counter() - t0)
+                try:
+                    lines = open(os.path.join(tmp, "output.txt")).read().split("\n")
+                    ok = ok and p.returncode == 0 and lines[1] == "%d %g" % (one.offset, one.score) and \
+                        lines[0] == h2[:one.char_offset].decode() + chr(one.ch) + h2[one.char_offset + 1:].decode()
+                    inner.append(float(p.stdout.split("total time:")[1].split()[0]))
+                except (OSError, IndexError, ValueError):
+                    ok = False
+            drop_in = {"wall_ms": 1e3 * sorted(walls)[1], "program_total_time_ms": 1e3 * sorted(inner)[1] if len(inner) == 3 else None,
+                       "output_equals_search": bool(ok),
+                       "note": "psa_main on a 1M x 10k input.txt, all offsets on the GPU: process start -> output.txt closed "
+                               "(median of 3 runs; HIP runtime + context creation dominate); program_total_time = the program's "
+                               "own 'total time' line = the reference's timed region cpu_funcs.c:57-62 in a fresh process"}
+
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     if os.path.exists(tpath):
@@ -715,6 +742,8 @@ def main():
         line["shard_emulation"] = shard_emulation
     if low_entropy:
         line["low_entropy_acgt"] = low_entropy
+    if drop_in:
+        line["drop_in_program"] = drop_in
     if emulated:
         line["config"]["emulated_world"] = args.emulate_world
     if cpu:
@@ -727,6 +756,8 @@ def main():
                       verified["gpu_run_program_equals_psa_search"] and verified["duo_retries"] == 0 and
                       verified["sequential_engine_fallbacks"] == 0)
     if sequential and not sequential["equals_filter_engine"]:
+        failed = True
+    if drop_in and not drop_in["output_equals_search"]:
         failed = True
     if rank == 0:
         print(json.dumps(line), flush=True)
