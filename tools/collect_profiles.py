@@ -27,17 +27,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "profiles")
 
 
+def newest(paths):
+    return max(paths, key=os.path.getmtime) if paths else None
+
+
 def main():
     tag = sys.argv[1]
     prefix = sys.argv[2] if len(sys.argv) > 2 else "prof_" + tag
     src = os.path.join(ROOT, "gpurun_out")
     os.makedirs(OUT, exist_ok=True)
     for sub, name in (("_stats", f"{tag}_kernel_stats.csv"), ("_twin", f"{tag}_twin_kernel_stats.csv")):
-        stats = glob.glob(os.path.join(src, prefix + sub, "*", "*_kernel_stats.csv"))
+        stats = newest(glob.glob(os.path.join(src, prefix + sub, "*", "*_kernel_stats.csv")))
         if stats:
-            shutil.copy(stats[0], os.path.join(OUT, name))
+            shutil.copy(stats, os.path.join(OUT, name))
     acc = collections.defaultdict(list)
-    for f in sorted(glob.glob(os.path.join(src, prefix + "_pmc*", "*", "*_counter_collection.csv"))):
+    # gpurun merges every call's output into gpurun_out/, so a pass directory holds one file per profiling run of the
+    # round: only the NEWEST run of each pass counts (earlier ones ran earlier kernels)
+    for d in sorted(glob.glob(os.path.join(src, prefix + "_pmc*"))):
+        f = newest(glob.glob(os.path.join(d, "*", "*_counter_collection.csv")))
+        if not f:
+            continue
         for row in csv.DictReader(open(f)):
             acc[(row["Kernel_Name"], row["Counter_Name"])].append(float(row["Counter_Value"]))
     with open(os.path.join(OUT, f"{tag}_counters.csv"), "w", newline="") as fh:
