@@ -495,6 +495,13 @@ struct psa_context {
     int         reselects = 0;               // filter searches whose selection ran twice (overflow against the running bound)
     int         unfused = 0;                 // single filter searches finished by psa_rescore_kernel, not inside the count kernel
     int         raw_retries = 0;             // one-shot searches (psa_search_device) redone through the two-launch path
+    // one-shot searches: arrival counter of the workgroups that write Seq2's class order (monotonic; raw_arrived = what
+    // it holds when no launch is in flight), and how many workgroups do that (debug library: 0 = every workgroup itself)
+    unsigned*   d_raw_arrivals = nullptr;
+    unsigned    raw_arrived = 0;
+    int         raw_converters = 16;         // at most (as many as the tiles leave CUs free)
+    bool        raw_force_timeout = false;   // debug library only: the tiles wait for one converter more than there is
+    int         cus = 256;                   // CUs of the device
     int         seq = 0;                     // sequence number of the last search enqueued
     // device groups: the final kernel of a single search also writes its 32-byte record here (device memory)
     psa_result* record_out = nullptr;
@@ -1258,6 +1265,9 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.classes_w = nullptr;
     a.bad = c->d_bad;
     a.n1 = a.m2 = a.class_total = 0;
+    a.raw_arrivals = nullptr;
+    a.raw_base = 0u;
+    a.raw_converters = a.raw_expected = 0;
     const dim3 grid(p.ntiles, p.nchunks);
     if (raw) {
         if (!fused || s2 || s.s2cls != s.d_s2cls) { set_last_error("internal: a raw launch is a fused single search"); return PSA_ERR_STATE; }
@@ -1271,14 +1281,33 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
         a.tail.n1 = raw->n;
         a.tail.s1 = raw->seq1;
         a.tail.s2 = raw->seq2;
+        {
+            if (!c->d_raw_arrivals) {
+                PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_raw_arrivals), 64));
+                PSA_HIP(hipMemsetAsync(c->d_raw_arrivals, 0, 64, stream));
+                c->raw_arrived = 0u;
+            }
+            // converter workgroups in front of the tiles: on the CUs the tiles leave free (at most 16), at least as many
+            // as keep a thread's share within kRawPerThread positions
+            const long long tiles = (long long)p.ntiles * p.nchunks;
+            const int need = (a.class_total + psa::kUnroll + 1024 * psa::kRawPerThread - 1) / (1024 * psa::kRawPerThread);
+            const long long spare = (long long)c->cus - tiles;
+            int conv = (int)std::max<long long>(need, std::min<long long>(c->raw_converters, spare > 0 ? spare : 8));
+            a.raw_converters = conv;
+            a.raw_expected = conv + (c->raw_force_timeout ? 1 : 0);
+            a.raw_arrivals = c->d_raw_arrivals;
+            a.raw_base = c->raw_arrived;
+        }
         if (!c->granted16_raw) {
             PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16, true>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, psa::kCountLdsBytes));   // (+ 2.3 KB static)
             c->granted16_raw = true;
         }
-        hipLaunchKernelGGL((psa::psa_count_kernel<16, true>), grid, dim3(16 * 64), p.lds_bytes, stream, a);
+        hipLaunchKernelGGL((psa::psa_count_kernel<16, true>), dim3(p.ntiles + a.raw_converters, p.nchunks), dim3(16 * 64), p.lds_bytes,
+                           stream, a);
         c->last_kernel = "psa_count_kernel<16, raw>";
         PSA_HIP(hipGetLastError());
+        c->raw_arrived += (unsigned)a.raw_converters;           // every converter arrives, however the search ends
         return PSA_OK;
     }
     // dynamic LDS above 64 KB has to be granted per kernel (and device: the flags live in the context)
@@ -1546,6 +1575,7 @@ psa_status psa_create(int device, void* stream, psa_context** out)
             PSA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
             c->own_stream = true;
         }
+        if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->cus < 1) c->cus = 256;
         PSA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
         PSA_HIP(hipStreamCreateWithFlags(&c->twin, hipStreamNonBlocking));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_pair), sizeof(double) * psa::kRow * psa::kRow));
@@ -1598,6 +1628,8 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     if (const char* r = std::getenv("PSA_DUO_SKEW")) c->duo_skew_ticks = std::max(0, std::atoi(r));
     if (const char* r = std::getenv("PSA_DUO_FORCE_TIMEOUT")) c->duo_force_timeout = std::atoi(r) != 0;
     if (const char* r = std::getenv("PSA_STREAM_FORCE_TIMEOUT")) c->stream_force_timeout = std::atoi(r) != 0;
+    if (const char* r = std::getenv("PSA_RAW_CONVERTERS")) c->raw_converters = std::max(1, std::min(1024, std::atoi(r)));
+    if (const char* r = std::getenv("PSA_RAW_FORCE_TIMEOUT")) c->raw_force_timeout = std::atoi(r) != 0;
 #endif
     *out = c;
     return PSA_OK;
@@ -1641,6 +1673,7 @@ void psa_destroy(psa_context* c)
     if (c->h_stage) (void)hipHostFree(c->h_stage);
     if (c->h_ctl) (void)hipHostFree(c->h_ctl);
     (void)hipFree(c->d_ctl);
+    (void)hipFree(c->d_raw_arrivals);
     if (c->h_bad) (void)hipHostFree(c->h_bad);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);

@@ -611,6 +611,7 @@ constexpr int kXSlotDwords = 2 * kCounters * kXKwDwords;        // one wave: 422
 constexpr int kXBytes = 8 * kXSlotDwords * 4;                   // 135,168
 static_assert(kPlanes == 10 && kXBytes >= kPlaneBytes, "exchange area: ten-plane counters, behind the plane rows' end");
 constexpr int kCellOffset = kXBytes;
+constexpr int kRawPerThread = 4;    // raw launches: positions of Seq2's class order one thread of a converter workgroup writes
 constexpr int kCountLdsBytes = kCellOffset + kCellDwords * 4;   // dynamic LDS of psa_count_kernel: 159,744 bytes
 
 // 16 plane words (planes 0..15 of 32 positions) -> 16 dwords, dword t = count(t) | count(t+16) << 16:
@@ -1790,6 +1791,12 @@ struct CountArgs {
     unsigned*   classes_w;            // = classes, writable
     int*        bad;                  // alphabet flag (bit 0 Seq1, bit 1 Seq2)
     int         n1, m2, class_total;
+    // raw launches: the grid's first `raw_converters` (>= 1) workgroups (row 0) are not tiles: they write a slice of Seq2's
+    // class order each and arrive on `raw_arrivals` (monotonic: `raw_base` = its value before this launch)
+    unsigned*   raw_arrivals;
+    unsigned    raw_base;
+    int         raw_converters;
+    int         raw_expected;         // = raw_converters (the debug library can ask for one more: the wait then gives up)
     RescoreArgs tail;
 };
 
@@ -1807,7 +1814,60 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tile_o0 = a.base + blockIdx.x * kTileStride;     // absolute offset of word 0, bit 0 (multiple of 32)
+    // Raw launches: the first raw_converters workgroups of the grid's row 0 are not tiles — they
+    // write Seq2's symbols in the count loop's class order, ONCE for everybody (a byte load and a write-through store per
+    // position, ~3 us on CUs the tiles leave free: 244 tiles on 256 CUs), arrive on raw_arrivals and leave; they are the
+    // first to be dispatched and wait for nobody.  The tile workgroups build their planes meanwhile and then wait for the
+    // arrivals, which are there by then.  (First form: every tile workgroup wrote all 40 KB itself, staged through LDS —
+    // 4.3 us per workgroup, prologue 8.6 us instead of 5.2.  Tried in between: the slices written by one wave of each of
+    // 128 tile workgroups — 128 arrivals on one counter under 244 pollers took 6 us to become visible.)
+    const int conv_wgs = RAW ? a.raw_converters : 0;
+    const int tile_x = (int)blockIdx.x - conv_wgs;
+    const int ntiles_x = (int)gridDim.x - conv_wgs;
+    if constexpr (RAW) if (tile_x < 0) {
+        if (blockIdx.y != 0) return;
+        const int total = a.class_total + kUnroll;
+        const int per = (total + conv_wgs - 1) / conv_wgs;
+        const int j0 = (int)blockIdx.x * per;
+        const int j1 = j0 + per < total ? j0 + per : total;
+        const int cc = a.class_chars;
+        const float rcc = 1.0f / (float)cc;
+        // position j of the class order holds char i = 32 (c cc + kk) + 31 - cs with j = ((32 c + cs) cc + kk); up to
+        // kRawPerThread positions per thread (host), all their loads in flight together
+        int at[kRawPerThread];
+        unsigned char ch[kRawPerThread];
+#pragma unroll
+        for (int t = 0; t < kRawPerThread; ++t) {
+            const int j = j0 + tid + WAVES * 64 * t;
+            at[t] = -1;
+            ch[t] = 0;
+            if (j < j1 && j < a.class_total) {
+                int q = (int)((float)j * rcc);
+                int kk = j - q * cc;
+                if (kk < 0) { kk += cc; --q; }
+                if (kk >= cc) { kk -= cc; ++q; }
+                const int i = (((q >> 5) * cc + kk) << 5) + (kClasses - 1 - (q & 31));
+                if (i < a.m2) { at[t] = i; ch[t] = a.raw2[i]; }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < kRawPerThread; ++t) {
+            const int j = j0 + tid + WAVES * 64 * t;
+            if (j < j1) {
+                unsigned code = kCodePad;
+                if (at[t] >= 0) {
+                    code = ascii_code(ch[t]);
+                    if (code == (unsigned)kCodePad) atomicOr(a.bad, 2);              // a character of Seq2 outside [A-Z-]
+                }
+                __hip_atomic_store(a.classes_w + j, code << kRowShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every wave's stores have been performed,
+        __syncthreads();                                            // then ONE lane's arrival
+        if (tid == 0) __hip_atomic_fetch_add(a.raw_arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int tile_o0 = a.base + tile_x * kTileStride;         // absolute offset of word 0, bit 0 (multiple of 32)
     const int chunk_k0 = blockIdx.y * a.class_chars;           // first char k of every class in this chunk
     const int slot0 = (tile_o0 >> 5) + chunk_k0;               // first staged slot
     // rows are 4 KiB apart: a Seq2 symbol, stored as code << 12, is its row's byte offset.  (A packed-row variant
@@ -1867,26 +1927,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         };
         uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
         if (slot < a.lds_slots) fetch(slot, c0, c1);
-        // RAW: this thread's 16 chars of Seq2 (the first of them; asked for together with the Seq1 window)
-        unsigned r2[4] = {0x41414141u, 0x41414141u, 0x41414141u, 0x41414141u};
-        const bool raw2_aligned = RAW && (reinterpret_cast<size_t>(a.raw2) & 15) == 0;
-        auto fetch2 = [&](int i0) {
-            if (raw2_aligned && i0 + 16 <= a.m2) {
-                const uint4 q = *reinterpret_cast<const uint4*>(a.raw2 + i0);
-                r2[0] = q.x; r2[1] = q.y; r2[2] = q.z; r2[3] = q.w;
-            } else {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    unsigned v = 0u;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v |= (i0 + 4 * q + r < a.m2 ? (unsigned)a.raw2[i0 + 4 * q + r] : (unsigned)'A') << (8 * r);
-                    r2[q] = v;
-                }
-            }
-        };
-        if constexpr (RAW) {
-            if (tid * 16 < a.m2) fetch2(tid * 16);
-        }
         if constexpr (!RAW) {
             if (tid < 64) s_planes[tid] = a.symbol_planes[tid];
         } else if (tid < 256) {
@@ -1896,59 +1936,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
             s_planes[256 + tid] = real ? a.symbol_planes[32 + code] : 0u;
         }
         __syncthreads();
-        if constexpr (RAW) {
-            // Seq2's symbols in the count loop's class order (class_index), as psa_encode_seq2_kernel writes them.  Every
-            // workgroup writes ALL of them and reads them back through the scalar cache: what a workgroup reads is its
-            // own store or another workgroup's store of the same value.  The class order is a stride-32 permutation:
-            // the codes are staged in LDS in natural order (in the count cells, which are not needed before the main
-            // loop ends; 4 bytes of padding per 32 codes keep the strided reads off each other's banks) so that the
-            // global stores are coalesced.
-            unsigned char* stage = reinterpret_cast<unsigned char*>(cells);
-            const bool staged = a.m2 + (a.m2 >> 3) + 64 <= kCellDwords * 4;
-            if (staged) {
-                for (int i0 = tid * 16; i0 < a.m2; i0 += WAVES * 64 * 16) {
-                    if (i0 != tid * 16) fetch2(i0);
-                    bool any_bad = false;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        unsigned codes = 0u;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const unsigned code = ascii_code((r2[q] >> (8 * r)) & 0xffu);
-                            any_bad |= code == (unsigned)kCodePad;
-                            codes |= code << (8 * r);
-                        }
-                        const int i = i0 + 4 * q;
-                        *reinterpret_cast<unsigned*>(stage + i + 4 * (i >> 5)) = codes;
-                    }
-                    if (any_bad) atomicOr(a.bad, 2);              // a character of Seq2 outside [A-Z-]
-                }
-                __syncthreads();
-            }
-            // position j of the class order holds char i = 32 (c cc + kk) + 31 - cs with j = ((32 c + cs) cc + kk):
-            // one division by cc (a float estimate, corrected)
-            const int total = a.class_total + kUnroll;
-            const int cc = a.class_chars;
-            const float rcc = 1.0f / (float)cc;
-            for (int j = tid; j < total; j += WAVES * 64) {
-                unsigned code = kCodePad;
-                if (j < a.class_total) {
-                    int q = (int)((float)j * rcc);
-                    int kk = j - q * cc;
-                    if (kk < 0) { kk += cc; --q; }
-                    if (kk >= cc) { kk -= cc; ++q; }
-                    const int i = (((q >> 5) * cc + kk) << 5) + (kClasses - 1 - (q & 31));
-                    if (i < a.m2) {
-                        if (staged) code = stage[i + 4 * (i >> 5)];
-                        else {
-                            code = ascii_code(a.raw2[i]);
-                            if (code == (unsigned)kCodePad) atomicOr(a.bad, 2);
-                        }
-                    }
-                }
-                a.classes_w[j] = code << kRowShift;
-            }
-        }
         const unsigned* tab = s_planes + (RAW ? 256 : 32) * hi_half;
         unsigned* dst = reinterpret_cast<unsigned*>(lds) + hi_half;
         unsigned seen = 0u;
@@ -1970,10 +1957,25 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         }
         if constexpr (RAW) {
             if (seen >> 31) atomicOr(a.bad, 1);             // a character of Seq1 outside [A-Z-]
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's symbol stores have reached the L2
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's symbol stores have been performed
         }
     }
     __syncthreads();
+    if constexpr (RAW) {
+        // everybody waits until all converters have arrived: the symbols are complete (and, written through, in memory)
+        if (tid == 0) {
+            int spins = 0;
+            while (__hip_atomic_load(a.raw_arrivals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.raw_base <
+                   (unsigned)a.raw_expected) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1 << 17)) {                // ~0.1 s: never expected; the host redoes the search with an
+                    atomicOr(a.bad, 16);                  // encode launch in front (psa_raw_retry_count)
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+    }
     PSA_PHASE(1);
 
     SlicedCounter cnt[2][kCounters];     // [word][n_lo, n_hi, n_both]
@@ -2034,7 +2036,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     unsigned n[kCounters][kPer];
     read_cells<kPer>(n, cells, kTileWords, o_local);
     if (!a.inline_select || gridDim.y > 1) {
-        unsigned long long* dst = a.partial + (size_t)blockIdx.y * a.span_pad + (size_t)blockIdx.x * kTile + o_local;
+        unsigned long long* dst = a.partial + (size_t)blockIdx.y * a.span_pad + (size_t)tile_x * kTile + o_local;
         // write-through (sc1) stores: they leave the XCD's L2 at once, so the hand-off below needs no L2 write-back
 #pragma unroll
         for (int e = 0; e < kPer; ++e)
@@ -2051,10 +2053,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
-            const int arrived = __hip_atomic_fetch_add(a.tile_arrivals + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int arrived = __hip_atomic_fetch_add(a.tile_arrivals + tile_x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_last_chunk = arrived == (int)gridDim.y - 1;
             if (s_last_chunk) {
-                __hip_atomic_store(a.tile_arrivals + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.tile_arrivals + tile_x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         }
@@ -2062,7 +2064,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         if (!s_last_chunk) return;
         for (int c = 0; c < (int)gridDim.y; ++c) {
             if (c == (int)blockIdx.y) continue;
-            const unsigned long long* src = a.partial + (size_t)c * a.span_pad + (size_t)blockIdx.x * kTile + o_local;
+            const unsigned long long* src = a.partial + (size_t)c * a.span_pad + (size_t)tile_x * kTile + o_local;
 #pragma unroll
             for (int e = 0; e < kPer; ++e) {
                 const unsigned long long v = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2078,7 +2080,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     double up[2][kPer];
     for (int mode = 0; mode < a.nmodes; ++mode) {
         // offsets relative to the range's first one; the tile answers for its first kTileStride positions
-        const double pess = thread_bounds<kPer>(a.sel[mode].bounds, n, (int)blockIdx.x * kTileStride + o_local - a.lead,
+        const double pess = thread_bounds<kPer>(a.sel[mode].bounds, n, tile_x * kTileStride + o_local - a.lead,
                                                 a.span, kTileStride - o_local, up[mode]);
         unsigned long long key = order_key(pess);
         key = wave_max_u64(key);
@@ -2102,7 +2104,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
             if (up[mode][e] >= need) {
                 const int slot = atomicAdd(sel.cand_count, 1);
                 if (slot < a.cap) {
-                    store_agent(sel.cand + slot, a.first + (int)blockIdx.x * kTileStride + o_local + e - a.lead);
+                    store_agent(sel.cand + slot, a.first + tile_x * kTileStride + o_local + e - a.lead);
                     store_agent(sel.cand_upper + slot, up[mode][e]);
                 }
             }
@@ -2117,7 +2119,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     __syncthreads();
     if (tid == 0) {
         const int arrived = __hip_atomic_fetch_add(a.tail.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last_tile = arrived == (int)gridDim.x - 1;
+        s_last_tile = arrived == ntiles_x - 1;
         if (s_last_tile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();

@@ -661,6 +661,31 @@ def test_one_shot_search_from_raw_ascii(psa, oracle, reference_records):
         assert c.raw_retry_count() == before and c.fallback_count() == 0
 
 
+def test_one_shot_search_whose_wait_gives_up_is_redone(psa_debug, monkeypatch):
+    """A one-shot search's tile workgroups wait for the converter workgroups that write Seq2's class order (a bounded
+    spin).  The debug library makes them wait for one converter more than there is: every workgroup gives up, the tail
+    carries bad |= 16, and the host redoes the search through an encode launch + a search launch — same answer."""
+    import torch
+    psa = psa_debug
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch, r.pairs)
+    n, m = 300_000, 2500
+    s1, s2 = psa.generate_sequence(95, n), psa.generate_sequence(96, m)
+    t1 = torch.frombuffer(bytearray(s1), dtype=torch.uint8).cuda()
+    t2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    with psa.Context(0) as c:
+        c.set_weights(W_README, True)
+        want = key(c.search_device(t1.data_ptr(), n, t2.data_ptr(), m))
+        assert c.raw_retry_count() == 0
+    monkeypatch.setenv("PSA_RAW_FORCE_TIMEOUT", "1")
+    with psa.Context(0) as c:
+        c.set_weights(W_README, True)
+        assert key(c.search_device(t1.data_ptr(), n, t2.data_ptr(), m)) == want
+        assert c.raw_retry_count() == 1
+        assert key(c.search_device(t1.data_ptr(), n, t2.data_ptr(), m, 1000, 200_000)) == key(c.search(1000, 200_000))
+        assert c.raw_retry_count() == 2
+
+
 def test_set_sequences_equals_the_two_setters(psa):
     """psa_set_sequences / psa_set_sequences_device (one encode launch for both sequences) == psa_set_seq1 + psa_set_seq2,
     for adjacent host buffers (one copy command), separate ones, device buffers, and a bad character in either."""

@@ -47,6 +47,15 @@ for k, name in enumerate(names):
     d = (ts[:, k + 1] - ts[:, k]) / 100.0
     print(f"{name:44s} mean {d.mean():7.2f}  min {d.min():7.2f}  max {d.max():7.2f} us")
 print("result", r)
+if raw:
+    full0 = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
+    ex = full0[300:300 + len(ts)]
+    for k, name in enumerate(["converter wave: symbol stores issued", "last wave: plane work done, stores drained (arrival next)",
+                              "plane build's barrier passed (wait for the arrivals next)"]):
+        d = (ex[:, k] - ts[:, 0]) / 100.0
+        d = d[ex[:, k] > 0]
+        if len(d):
+            print(f"raw  {name:62s} mean {d.mean():6.2f}  min {d.min():6.2f}  max {d.max():6.2f} us after the workgroup's start")
 tail = ts[ts[:, 7] > 0]
 for row in tail:     # the workgroup that finished the search (finish_search)
     print(f"fused tail (last tile workgroup): select end -> tail written {(row[7] - row[6]) / 100.0:.2f} us; "
