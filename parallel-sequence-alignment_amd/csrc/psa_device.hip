@@ -609,6 +609,64 @@ psa_status report_bad(psa_context* c)
     return PSA_ERR_ALPHABET;
 }
 
+// The pinned control words of the encode launches and their device-side companions: pinned word 0 = the host's copy
+// progress of a streamed transfer, pinned word 8 (a cache line of its own) = an encode launch's "done" word (ticket and
+// alphabet flag, written by its last workgroup); device word 0 = the poller's copy of the progress, word 8 = the
+// workgroups' arrival counter.
+psa_status ensure_ctl(psa_context* c)
+{
+    if (c->h_ctl) return PSA_OK;
+    PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ctl), 128, hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(c->h_ctl, 0, 128);
+    PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->hd_ctl), c->h_ctl, 0));
+    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_ctl), 128));
+    PSA_HIP(hipMemsetAsync(c->d_ctl, 0, 128, c->stream));
+    return PSA_OK;
+}
+
+unsigned next_ticket(psa_context* c)
+{
+    c->stream_ticket = (c->stream_ticket + 1) & 0xffffffu;
+    if (c->stream_ticket == 0) c->stream_ticket = 1;
+    return c->stream_ticket;
+}
+
+// `report`: the launch's last workgroup writes its ticket and the alphabet flag to the pinned "done" word (wait_done)
+psa_status done_word(psa_context* c, bool report, psa::DoneWord* d)
+{
+    d->arrivals = nullptr;
+    d->host_done = nullptr;
+    d->bad = c->d_bad;
+    d->ticket = 0u;
+    if (!report) return PSA_OK;
+    PSA_TRY(ensure_ctl(c));
+    d->arrivals = reinterpret_cast<unsigned*>(c->d_ctl + 8);
+    d->host_done = c->hd_ctl + 8;
+    d->ticket = next_ticket(c);
+    return PSA_OK;
+}
+
+// The encode launch in flight reports through the "done" word: watching it returns a few microseconds before a copy
+// of the flag + the stream's completion signal would (a launch that takes longer than 2 ms falls back to exactly that).
+psa_status wait_done(psa_context* c)
+{
+    const volatile unsigned long long* done = c->h_ctl + 8;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int k = 0; k < 256; ++k) {
+            const unsigned long long w = *done;
+            if ((unsigned)(w >> 40) == c->stream_ticket) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                *c->h_bad = (int)(w & 0xffffffu);
+                return PSA_OK;
+            }
+            __builtin_ia32_pause();
+        }
+        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 2000.0) break;
+    }
+    return check_bad_now(c);
+}
+
 // Seq1: ASCII -> symbol codes (the class planes are built per workgroup inside the count kernel)
 psa_status seq1_args(psa_context* c, const void* d_raw, int n, psa::PrepareArgs* a)
 {
@@ -627,11 +685,13 @@ psa_status seq1_args(psa_context* c, const void* d_raw, int n, psa::PrepareArgs*
     return PSA_OK;
 }
 
-psa_status encode_seq1(psa_context* c, const void* d_raw, int n)
+psa_status encode_seq1(psa_context* c, const void* d_raw, int n, bool report = false)
 {
     psa::PrepareArgs a;
+    psa::DoneWord done;
     PSA_TRY(seq1_args(c, d_raw, n, &a));
-    hipLaunchKernelGGL(psa::psa_prepare_seq1_kernel, dim3((c->nslots + 255) / 256), dim3(256), 0, c->stream, a);
+    PSA_TRY(done_word(c, report, &done));
+    hipLaunchKernelGGL(psa::psa_prepare_seq1_kernel, dim3((c->nslots + 255) / 256), dim3(256), 0, c->stream, a, done);
     PSA_HIP(hipGetLastError());
     c->n = n;
     return PSA_OK;
@@ -684,28 +744,32 @@ void seq2_encoded(SearchSlot& s, int m, const FilterPlan& p)
     s.s2cls = s.d_s2cls;
 }
 
-psa_status encode_seq2(psa_context* c, SearchSlot& s, const void* d_raw, int m, hipStream_t stream)
+psa_status encode_seq2(psa_context* c, SearchSlot& s, const void* d_raw, int m, hipStream_t stream, bool report = false)
 {
     psa::Seq2Args a;
+    psa::DoneWord done;
     FilterPlan p;
     PSA_TRY(seq2_args(s, d_raw, m, c->n, c->d_bad, &a, &p));
-    hipLaunchKernelGGL(psa::psa_encode_seq2_kernel, dim3((s.m_cap / 16 + 255) / 256), dim3(256), 0, stream, a);
+    PSA_TRY(done_word(c, report, &done));
+    hipLaunchKernelGGL(psa::psa_encode_seq2_kernel, dim3((s.m_cap / 16 + 255) / 256), dim3(256), 0, stream, a, done);
     PSA_HIP(hipGetLastError());
     seq2_encoded(s, m, p);
     return PSA_OK;
 }
 
 // both sequences of a search (slot 0) by one launch
-psa_status encode_pair(psa_context* c, const void* d_raw1, int n, const void* d_raw2, int m)
+psa_status encode_pair(psa_context* c, const void* d_raw1, int n, const void* d_raw2, int m, bool report = false)
 {
     SearchSlot& s = c->slot[0];
     psa::PrepareArgs a1;
     psa::Seq2Args a2;
+    psa::DoneWord done;
     FilterPlan p;
     PSA_TRY(seq1_args(c, d_raw1, n, &a1));
     PSA_TRY(seq2_args(s, d_raw2, m, n, c->d_bad, &a2, &p));
+    PSA_TRY(done_word(c, report, &done));
     const int blocks1 = (c->nslots + 255) / 256, blocks2 = (s.m_cap / 16 + 255) / 256;
-    hipLaunchKernelGGL(psa::psa_encode_pair_kernel, dim3(blocks1 + blocks2), dim3(256), 0, c->stream, a1, a2, blocks1);
+    hipLaunchKernelGGL(psa::psa_encode_pair_kernel, dim3(blocks1 + blocks2), dim3(256), 0, c->stream, a1, a2, blocks1, done);
     PSA_HIP(hipGetLastError());
     c->n = n;
     seq2_encoded(s, m, p);
@@ -811,47 +875,15 @@ const StreamKnobs& stream_knobs()
     return k;
 }
 
-// The streamed launch's last workgroup writes ticket << 40 | alphabet flag to the pinned "done" word: watching it
-// returns a few microseconds before a copy of the flag + the stream's completion signal would (a stalled launch falls
-// back to exactly that).
-psa_status stream_wait_done(psa_context* c)
-{
-    const volatile unsigned long long* done = c->h_ctl + 8;
-    const auto t0 = std::chrono::steady_clock::now();
-    for (;;) {
-        for (int k = 0; k < 256; ++k) {
-            const unsigned long long w = *done;
-            if ((unsigned)(w >> 40) == c->stream_ticket) {
-                std::atomic_thread_fence(std::memory_order_acquire);
-                *c->h_bad = (int)(w & 0xffffffu);
-                return PSA_OK;
-            }
-            __builtin_ia32_pause();
-        }
-        if (std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 2000.0) break;
-    }
-    return check_bad_now(c);
-}
-
 psa_status stream_pair(psa_context* c, const char* seq1, size_t limit1, bool find_nul, const char* seq2, size_t m, int* n_out)
 {
     SearchSlot& s = c->slot[0];
     const auto t_enter = std::chrono::steady_clock::now();
-    if (!c->h_ctl) {
-        // pinned: word 0 = the host's progress, word 8 (a cache line of its own) = the launch's "done" word;
-        // device: word 0 = the poller's copy of the progress, word 8 = the workgroups' arrival counter
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ctl), 128, hipHostMallocMapped | hipHostMallocCoherent));
-        std::memset(c->h_ctl, 0, 128);
-        PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->hd_ctl), c->h_ctl, 0));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_ctl), 128));
-        PSA_HIP(hipMemsetAsync(c->d_ctl, 0, 128, c->stream));
-    }
+    PSA_TRY(ensure_ctl(c));
     const size_t second = ((limit1 + 63) & ~(size_t)63) + 64;
     PSA_TRY(ensure_stage(c, second + m));
     c->stage_second = second;
-    c->stream_ticket = (c->stream_ticket + 1) & 0xffffffu;
-    if (c->stream_ticket == 0) c->stream_ticket = 1;
-    const unsigned ticket = c->stream_ticket;
+    const unsigned ticket = next_ticket(c);
     std::memcpy(c->h_stage + second, seq2, m);
     if (!c->stream_force_timeout) stream_publish(c, ticket, 0, false);
 
@@ -863,7 +895,7 @@ psa_status stream_pair(psa_context* c, const char* seq1, size_t limit1, bool fin
     const int blocks1 = (c->nslots + 255) / 256, blocks2 = (s.m_cap / 16 + 255) / 256;
     hipLaunchKernelGGL(psa::psa_encode_pair_streamed_kernel, dim3(1 + blocks1 + blocks2), dim3(256), 0, c->stream, a1, a2, blocks1,
                        c->hd_ctl, c->d_ctl, ticket, c->stream_force_timeout ? 0 : (1 << 16),   // 2^16 polls of ~2 us
-                       reinterpret_cast<unsigned*>(c->d_ctl + 8), c->hd_ctl + 8);
+                       psa::DoneWord{reinterpret_cast<unsigned*>(c->d_ctl + 8), c->hd_ctl + 8, c->d_bad, ticket});
     const hipError_t launched = hipGetLastError();
     // (whatever happens from here on, the kernel is told that nothing more will come)
     size_t done = 0;
@@ -1724,8 +1756,8 @@ psa_status psa_set_seq1(psa_context* c, const char* seq1, int n)
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     PSA_TRY(stage_pinned_pair(c, seq1, (size_t)n, seq1 + n, 0));
-    PSA_TRY(encode_seq1(c, c->hd_stage, n));                // reads the pinned host copy over PCIe
-    PSA_TRY(check_bad_now(c));
+    PSA_TRY(encode_seq1(c, c->hd_stage, n, true));          // reads the pinned host copy over PCIe
+    PSA_TRY(wait_done(c));
     return report_bad(c);
 }
 
@@ -1735,8 +1767,8 @@ psa_status psa_set_seq2(psa_context* c, const char* seq2, int m)
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     PSA_TRY(stage_pinned_pair(c, seq2, (size_t)m, seq2 + m, 0));
-    PSA_TRY(encode_seq2(c, c->slot[0], c->hd_stage, m, c->stream));
-    PSA_TRY(check_bad_now(c));
+    PSA_TRY(encode_seq2(c, c->slot[0], c->hd_stage, m, c->stream, true));
+    PSA_TRY(wait_done(c));
     return report_bad(c);
 }
 
@@ -1759,14 +1791,14 @@ psa_status psa_set_sequences(psa_context* c, const char* seq1, int n, const char
         int got = 0;
         c->stream_gave_up = false;
         PSA_TRY(stream_pair(c, seq1, (size_t)n, false, seq2, (size_t)m, &got));
-        PSA_TRY(stream_wait_done(c));
+        PSA_TRY(wait_done(c));
         const psa_status st = report_bad(c);
         if (!c->stream_gave_up) return st;
         c->stream_gave_up = false;                  // (never expected: the host thread stalled for > 0.1 s mid-copy)
     }
     PSA_TRY(stage_pinned_pair(c, seq1, (size_t)n, seq2, (size_t)m));
-    PSA_TRY(encode_pair(c, c->hd_stage, n, c->hd_stage + c->stage_second, m));     // reads the host copy over PCIe
-    PSA_TRY(check_bad_now(c));
+    PSA_TRY(encode_pair(c, c->hd_stage, n, c->hd_stage + c->stage_second, m, true));     // reads the host copy over PCIe
+    PSA_TRY(wait_done(c));
     return report_bad(c);
 }
 

@@ -228,9 +228,36 @@ __device__ __forceinline__ void prepare_seq1_slot(const PrepareArgs& a, int slot
     dst[1] = make_uint4(cw[4], cw[5], cw[6], cw[7]);
 }
 
-__global__ __launch_bounds__(256) void psa_prepare_seq1_kernel(PrepareArgs a)
+// The host-sequence setters have to report a character outside [A-Z-] before they return.  Instead of copying the flag
+// back and waiting for the stream (a copy command, its completion signal, the runtime's wake-up: ~8 us), the encode
+// launch's last workgroup to finish — `arrivals` (device, zero between launches) counts them — writes ticket << 40 | flag
+// to `host_done` in pinned memory, which the host polls.  host_done == NULL: nobody is waiting (device-sequence setters).
+struct DoneWord {
+    unsigned*           arrivals;
+    unsigned long long* host_done;
+    const int*          bad;
+    unsigned            ticket;
+};
+
+__device__ __forceinline__ void report_done(const DoneWord& d)
+{
+    if (!d.host_done) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave's stores and flag updates have been performed,
+    __syncthreads();                                      // then ONE lane's arrival
+    if (threadIdx.x == 0) {
+        const unsigned arrived = __hip_atomic_fetch_add(d.arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x * gridDim.y - 1) {
+            __hip_atomic_store(d.arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned flag = (unsigned)__hip_atomic_load(d.bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(d.host_done, ((unsigned long long)d.ticket << 40) | flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void psa_prepare_seq1_kernel(PrepareArgs a, DoneWord done)
 {
     prepare_seq1_slot(a, blockIdx.x * 256 + threadIdx.x);
+    report_done(done);
 }
 
 // ---- Seq2 of a single search: ASCII -> the three encodings the engines read ----------
@@ -287,16 +314,18 @@ __device__ __forceinline__ void encode_seq2_16(const Seq2Args& a, int i0)
     if (any_bad) atomicOr(a.bad, 2);
 }
 
-__global__ __launch_bounds__(256) void psa_encode_seq2_kernel(Seq2Args a)
+__global__ __launch_bounds__(256) void psa_encode_seq2_kernel(Seq2Args a, DoneWord done)
 {
     encode_seq2_16(a, (blockIdx.x * 256 + threadIdx.x) * 16);
+    report_done(done);
 }
 
 // both sequences of a search in ONE launch (psa_set_sequences*, gpu_run_program): blocks [0, blocks1) take Seq1
-__global__ __launch_bounds__(256) void psa_encode_pair_kernel(PrepareArgs a1, Seq2Args a2, int blocks1)
+__global__ __launch_bounds__(256) void psa_encode_pair_kernel(PrepareArgs a1, Seq2Args a2, int blocks1, DoneWord done)
 {
     if ((int)blockIdx.x < blocks1) prepare_seq1_slot(a1, blockIdx.x * 256 + threadIdx.x);
     else encode_seq2_16(a2, (((int)blockIdx.x - blocks1) * 256 + threadIdx.x) * 16);
+    report_done(done);
 }
 
 // ---- the same launch FOLLOWING the host's copy (psa_set_sequences, gpu_run_program on long sequences) -------------
@@ -367,14 +396,10 @@ __device__ __forceinline__ unsigned long long stream_wait(const unsigned long lo
     return s_word;
 }
 
-// `arrivals` (device, zero between launches) counts the workgroups that have finished; the last one hands the alphabet
-// flag to the host in `host_done` (pinned: ticket << 40 | flag), which psa_set_sequences polls instead of copying the
-// flag back and waiting for the stream (a copy command, its completion signal and the runtime's wake-up: ~8 us).
 __global__ __launch_bounds__(256) void psa_encode_pair_streamed_kernel(PrepareArgs a1, Seq2Args a2, int blocks1,
                                                                        const unsigned long long* host_word,
                                                                        unsigned long long* dev_word, unsigned ticket,
-                                                                       int spin_limit, unsigned* arrivals,
-                                                                       unsigned long long* host_done)
+                                                                       int spin_limit, DoneWord done)
 {
 #ifdef PSA_PHASE_TIMING
 #define PSA_EPHASE(k) do { if (threadIdx.x == 0 && blockIdx.x < 1000) g_phase_ts[blockIdx.x][k] = wall_clock64(); } while (0)
@@ -398,17 +423,7 @@ __global__ __launch_bounds__(256) void psa_encode_pair_streamed_kernel(PrepareAr
         (void)stream_wait(dev_word, ticket, 0ull, spin_limit, a2.bad);     // Seq2 is in place before the first publication
         encode_seq2_16(a2, ((block - blocks1) * 256 + threadIdx.x) * 16);
     }
-    // every wave's stores and flag updates have been performed, then ONE lane's arrival
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned arrived = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (arrived == gridDim.x - 1) {
-            __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const unsigned flag = (unsigned)__hip_atomic_load(a1.bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(host_done, ((unsigned long long)ticket << 40) | flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-    }
+    report_done(done);
 }
 
 // out[b] bit t = in[t] bit b  (recursive block swap, Hacker's Delight 7-3, mirrored)
