@@ -495,8 +495,8 @@ struct psa_context {
     int         reselects = 0;               // filter searches whose selection ran twice (overflow against the running bound)
     int         unfused = 0;                 // single filter searches finished by psa_rescore_kernel, not inside the count kernel
     int         raw_retries = 0;             // one-shot searches (psa_search_device) redone through the two-launch path
-    // one-shot searches: arrival counter of the workgroups that write Seq2's class order (monotonic; raw_arrived = what
-    // it holds when no launch is in flight), and how many workgroups do that (debug library: 0 = every workgroup itself)
+    // one-shot searches: arrival counter of the converter workgroups that write Seq2's class order in front of the tiles
+    // (monotonic; raw_arrived = what it holds when no launch is in flight), and how many of them a launch may have
     unsigned*   d_raw_arrivals = nullptr;
     unsigned    raw_arrived = 0;
     int         raw_converters = 16;         // at most (as many as the tiles leave CUs free)
