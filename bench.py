@@ -86,6 +86,11 @@ def parse_args(argv=None):
                     help="rehearsal on a one-GPU box: every rank uses device 0 (needs --backend gloo; not a scaling measurement)")
     ap.add_argument("--stub-search", action="store_true",
                     help="launcher / exchange rehearsal without a GPU: gloo, records made up from the query index")
+    ap.add_argument("--group-leg", action="store_true",
+                    help="internal: ONE process drives --gpus N devices through the library's own multi-GPU entry points "
+                         "(psa_search_sharded / psa_search_batch_sharded: launcher threads, RCCL all-gather) and prints the "
+                         "`c_abi_group` object; bench.py runs this as a child process and merges it into its line")
+    ap.add_argument("--no-group-leg", action="store_true", help="skip the c_abi_group child process")
     args = ap.parse_args(argv)
     if args.queries is None:
         args.queries = 256 if args.mode == "batch" else 1
@@ -258,6 +263,135 @@ def stub_main(args, world, rank):
     return 0 if ok else 1
 
 
+# --------------------------------------------------------------------------------------
+# c_abi_group: the library's own multi-GPU product path (one process, psa_group_*)
+# --------------------------------------------------------------------------------------
+def group_leg_main(args):
+    """BASELINE.json configs[3] and [4] through the C ABI's device group, in ONE process (a single process
+    drives the node's devices): psa_search_sharded — the offsets split by the reference's rank rule
+    (cpu_funcs.c:128-133), every device served by its own persistent launcher thread, one exchange of the 32-byte
+    records (RCCL ncclAllGather; cpu_funcs.c:71-94 replaced), psa_fold — and psa_search_batch_sharded (64 and 256 queries
+    dealt to the devices).  Answers are checked against a single context on device 0.
+    With N >= 2 visible devices the group is devices 0..N-1 with the RCCL exchange (and once more with the host exchange
+    for comparison).  On a ONE-GPU box the N-way path cannot run RCCL (one rank per GPU), so it is rehearsed with the host
+    exchange over N = 2, 4, 8 contexts on device 0 — that measures the host-side cost per call (issue time of the
+    launcher threads), not scaling — next to an RCCL group of the one device.  No torch in this process."""
+    import ctypes as C
+    import numpy as np
+    import psa_amd as psa
+
+    n, m = args.n, args.m
+    total = n - m + 1
+    ndev_visible = C.c_int(0)
+    try:
+        hip = C.CDLL("libamdhip64.so")
+        hip.hipGetDeviceCount(C.byref(ndev_visible))
+    except OSError:
+        pass
+    have = ndev_visible.value
+    if have < 1:
+        print(json.dumps({"error": "no HIP device visible"}))
+        return 1
+    want = args.gpus
+    h1 = psa.generate_sequence_np(SEED_SEQ1, n).tobytes()
+    nq_big = 256 if (n, m) == (1_000_000, 10_000) else min(256, args.queries or 256)
+    hq = [psa.generate_sequence_np(SEED_QUERY0 + q, m).tobytes() for q in range(nq_big)]
+
+    # the single-context answers
+    with psa.Context(0) as ctx:
+        ctx.set_weights(WEIGHTS, True)
+        ctx.set_seq1(h1)
+        ctx.set_seq2(hq[0])
+        ref0 = ctx.search(0, total)
+        ref_batch = ctx.search_batch(hq)
+        ref_hi, ref_lo = ctx.search_batch_minmax(hq[:64])
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+
+    def wall_us(fn, reps, warm=3):
+        t = []
+        for k in range(reps + warm):
+            t0 = time.perf_counter()
+            fn()
+            if k >= warm:
+                t.append(time.perf_counter() - t0)
+        return 1e6 * sorted(t)[len(t) // 2]
+
+    def run_group(devices, exchange, label):
+        out = {"devices": list(devices), "exchange": label}
+        with psa.Group(devices, exchange) as g:
+            g.set_weights(WEIGHTS, True)
+            g.set_seq1(h1)
+            g.set_seq2(hq[0])
+            res, shards = g.search(0, total)
+            ok = key(res) == key(ref0) and res.pairs == total * m
+            issue = []
+
+            def one():
+                g.search(0, total)
+                issue.append(g.last_timing()[0])
+            blocking = wall_us(one, 24)
+            issue = sorted(issue[3:])
+            out["sharded_search"] = {
+                "blocking_us": blocking, "host_issue_us": issue[len(issue) // 2], "host_issue_us_max": issue[-1],
+                "pairs_per_s": total * m / (blocking * 1e-6), "equals_single_context": bool(ok),
+                "shard_offsets": [psa.shard_range(total, len(devices), r) for r in (0, len(devices) - 1)]}
+            batches = {}
+            for nq in (64, nq_big):
+                got = g.search_batch(hq[:nq])
+                same = [key(r) for r in got] == [key(r) for r in ref_batch[:nq]]
+                ms = wall_us(lambda: g.search_batch(hq[:nq]), 3, warm=1) / 1e3
+                batches[str(nq)] = {"ms": ms, "pairs_per_s": nq * total * m / (ms * 1e-3), "equals_single_context": bool(same)}
+            hi, lo = g.search_batch(hq[:64], minmax=True)
+            batches["64_minmax_equals_single_context"] = bool([key(r) for r in hi] == [key(r) for r in ref_hi] and
+                                                              [key(r) for r in lo] == [key(r) for r in ref_lo])
+            out["batch_sharded"] = batches
+        out["ok"] = bool(out["sharded_search"]["equals_single_context"] and batches["64_minmax_equals_single_context"] and
+                         all(v["equals_single_context"] for k, v in batches.items() if isinstance(v, dict)))
+        return out
+
+    legs = []
+    if have >= 2 and want >= 2:
+        devs = list(range(min(want, have)))
+        legs.append(run_group(devs, psa.EXCHANGE_RCCL, "RCCL ncclAllGather over xGMI, one rank per GPU"))
+        legs.append(run_group(devs, psa.EXCHANGE_HOST, "host memory (comparison: same devices, no RCCL)"))
+        mode = f"{len(devs)} GPUs, one process"
+    else:
+        legs.append(run_group([0], psa.EXCHANGE_RCCL, "RCCL ncclAllGather, a communicator of ONE device"))
+        for k in (2, 4, 8):
+            legs.append(run_group([0] * k, psa.EXCHANGE_HOST,
+                                  f"host memory: {k} contexts on ONE GPU (rehearsal of the {k}-way path: host-side cost per call, "
+                                  f"not scaling — the {k} shard kernels share one GPU)"))
+        mode = "one GPU: N-way paths rehearsed with the host exchange"
+    print(json.dumps({"mode": mode, "visible_devices": have, "groups": legs, "ok": all(l["ok"] for l in legs),
+                      "note": "psa_search_sharded / psa_search_batch_sharded through psa.Group (ctypes): configs[3] = one blocking "
+                              "1M x 10k MAX search, offsets sharded; configs[4] = 64 / 256 queries dealt to the devices.  "
+                              "host_issue_us = from the call's entry until the LAST device's launch had been enqueued (persistent "
+                              "launcher thread per device; one thread issuing 8 launches in turn took ~40 us).  N > 1 with RCCL has "
+                              "only ever run where this object says exchange = RCCL with more than one device"}), flush=True)
+    return 0
+
+
+def run_group_leg(args, gpus):
+    """Child process (fresh HIP runtime, no torch): a hang or crash of the multi-GPU leg cannot take the headline line down."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--group-leg", "--gpus", str(gpus), "--n", str(args.n), "--m", str(args.m)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "ROLE_RANK", "LOCAL_WORLD_SIZE"):
+        env.pop(k, None)
+    try:
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+    except subprocess.TimeoutExpired:
+        return {"error": "the c_abi_group child process did not finish within 240 s", "ok": False}
+    for ln in reversed(p.stdout.splitlines()):
+        if ln.startswith("{"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                break
+    return {"error": f"c_abi_group child exited with {p.returncode}: {p.stderr[-600:]}", "ok": False}
+
+
+
 def median_us(fn, sync, reps=24, warm=4):
     """Median wall time of fn() in microseconds, device idle before every call."""
     t = []
@@ -274,6 +408,8 @@ def main():
     args = parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.group_leg:
+        raise SystemExit(group_leg_main(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -419,9 +555,42 @@ def main():
                      "unit": "char-pair scores/s",
                      "note": "the reference's timed region (cpu_funcs.c:57-62; SURVEY.md 8(d)): inputs in pageable host memory -> "
                              "every best mutant on the host: psa_set_seq1 + psa_search_batch, 1 MB + Q x 10 kB over PCIe per "
-                             "step.  `value` is the same step from HBM-resident inputs, which is what the bench contract asks "
-                             "for as the headline"}
+                             "step.  THIS `value` is the from-host-buffers (PCIe-inclusive) throughput; the line's top-level "
+                             "`value` is the same step from HBM-resident inputs, which the bench contract asks for as headline"}
         from_host_equal = [r.as_tuple() for r in fh] == [r.as_tuple() for r in (results[slot0:slot0 + qhi - qlo] if world > 1 else results)]
+
+    # ---- N > 1, batch mode: configs[3] as well — the OFFSETS of query 0 (and of 64 queries in flight) sharded over the
+    # ranks with the reference's rule (cpu_funcs.c:128-133), one exchange of the per-rank records, is_swapable fold
+    offset_shard = None
+    if world > 1 and args.mode == "batch" and not emulated:
+        s_lo, s_hi = psa.shard_range(total, world, rank)
+        nb = min(64, nq)
+
+        def shard_one():
+            rec = ctx.search_device(t1.data_ptr(), n, tq[0].data_ptr(), m, s_lo, s_hi)
+            return exchange_and_fold_many(psa, dist, torch, [rec], rank, world, True, xdev)
+
+        def shard_many():
+            ctx.set_seq1_device(t1.data_ptr(), n)
+            recs = ctx.search_batch_device(tq.data_ptr(), nb, m, m, s_lo, s_hi)
+            return exchange_and_fold_many(psa, dist, torch, recs, rank, world, True, xdev)
+        shard_one()
+        one_steps = 20
+        one_elapsed, one_out = timed(shard_one, one_steps)
+        shard_many()
+        many_steps = max(2, args.steps)
+        many_elapsed, many_out = timed(shard_many, many_steps)
+        offset_shard = {
+            "blocking_search_us": 1e6 * one_elapsed / one_steps,
+            "blocking_search_pairs_per_s": total * m * one_steps / one_elapsed,
+            "in_flight_queries": nb, "in_flight_ms_per_step": 1e3 * many_elapsed / many_steps,
+            "in_flight_pairs_per_s": nb * total * m * many_steps / many_elapsed,
+            "result_query0": {"offset": one_out[0].offset, "score": one_out[0].score},
+            "in_flight_query0_equals_blocking": (one_out[0].offset, one_out[0].score) == (many_out[0].offset, many_out[0].score),
+            "note": f"BASELINE.json configs[3]: offsets of one 1M x 10k MAX search split over {world} ranks (psa_shard_range), every "
+                    "rank searches its shard from raw ASCII in HBM, ONE all-reduce of the per-rank 32-byte records, is_swapable "
+                    "fold; blocking = one search at a time (latency-bound: ~45 us of a search do not shard), in flight = "
+                    f"{nb} queries per step on every rank's shard (throughput).  max over ranks, barrier on both sides"}
 
     cpu = cpu4 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -744,6 +913,8 @@ def main():
         line["low_entropy_acgt"] = low_entropy
     if drop_in:
         line["drop_in_program"] = drop_in
+    if offset_shard:
+        line["offset_shard"] = offset_shard
     if emulated:
         line["config"]["emulated_world"] = args.emulate_world
     if cpu:
@@ -759,13 +930,24 @@ def main():
         failed = True
     if drop_in and not drop_in["output_equals_search"]:
         failed = True
+    # ---- the library's own multi-GPU path (psa_search_sharded / psa_search_batch_sharded: launcher threads + RCCL
+    # all-gather inside libpsa_amd.so), driven by ONE child process over all `world` devices, after every rank has
+    # finished and the torch process group is gone (rank 0 only; the other ranks are idle or have exited)
+    ctx.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and not args.no_group_leg and not emulated and not args.share_gpu:
+        del t1, tq
+        torch.cuda.empty_cache()
+        group = run_group_leg(args, world)
+        line["c_abi_group"] = group
+        if not group.get("ok", False):
+            failed = True
     if rank == 0:
         print(json.dumps(line), flush=True)
         if failed:
-            print("bench.py: SELF-CHECK FAILED (see \"verified\")", file=sys.stderr)
-    ctx.close()
-    if dist:
-        dist.destroy_process_group()
+            print("bench.py: SELF-CHECK FAILED (see \"verified\" / \"c_abi_group\")", file=sys.stderr)
     if failed:
         raise SystemExit(1)
 

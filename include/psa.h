@@ -147,7 +147,13 @@ psa_status psa_set_batch_streams(psa_context* ctx, int streams);
 
 /* Search offsets [first_offset, last_offset) — the body of gpu_run_program.
  * psa_search blocks; psa_search_async enqueues on the context's stream and
- * psa_search_wait synchronises and returns the record. */
+ * psa_search_wait waits for the record and returns it.
+ * "Blocks" means: until the RESULT is on the host.  The search's last kernel writes its record into pinned host memory
+ * and the library watches that word; the kernel's last instructions (and the stream's completion signal) may follow a
+ * few microseconds after psa_search / psa_search_wait / psa_search_device have returned.  Everything the library itself
+ * does next is ordered behind it by the context's stream.  A caller that passed device buffers (psa_set_*_device,
+ * psa_search_device, psa_search_batch*_device) and wants to overwrite or free them from ANOTHER stream must
+ * synchronise with the context's stream first (hipStreamSynchronize, or an event). */
 psa_status psa_search(psa_context* ctx, int first_offset, int last_offset, psa_result* out);
 psa_status psa_search_async(psa_context* ctx, int first_offset, int last_offset);
 psa_status psa_search_wait(psa_context* ctx, psa_result* out);
@@ -194,12 +200,9 @@ psa_status psa_search_batch_minmax_device(psa_context* ctx, const void* d_querie
 psa_status psa_scores(psa_context* ctx, int first_offset, int last_offset,
                       double* scores, int32_t* char_offsets, int32_t* chs);
 
-/* Diagnostics of the filter engine (tests): its exact per-offset class counts
- * (how many of the m pairs are '*', ':' and '.'), and how many searches of this
- * context overflowed the candidate list and were redone by the sequential
- * engine.  Arrays are host memory of last-first entries; any may be NULL. */
-psa_status psa_debug_counts(psa_context* ctx, int first_offset, int last_offset,
-                            uint32_t* n_star, uint32_t* n_colon, uint32_t* n_dot);
+/* Health counters of the filter engine: how many searches of this context overflowed the candidate list and were
+ * redone by the sequential engine.  (The test hooks psa_debug_counts / psa_debug_rescore are not part of this
+ * library: include/psa_debug.h, libpsa_debug.so.) */
 int psa_fallback_count(psa_context* ctx);
 /* Filter searches of this context whose candidate selection ran twice: candidates are picked
  * against a running bound while the tiles finish; when that overflows the list, the selection
@@ -211,10 +214,6 @@ int psa_unfused_count(psa_context* ctx);
 /* Batches redone with the per-query count kernel because a wave-group barrier of the batch
  * count kernel gave up (never expected on a healthy device). */
 int psa_duo_retry_count(psa_context* ctx);
-/* The filter engine's exact re-score (total + best delta, cpu_funcs.c:299) of
- * up to 2048 arbitrary offsets, without the filter in front of it. */
-psa_status psa_debug_rescore(psa_context* ctx, const int32_t* offsets, int count, double* scores);
-
 /* ---------------------------------------------------------------------------
  * Device group: ONE search sharded over several GPUs of this node — the reference's
  * MPI layer (ranks, MPI_Bcast of ProgramData, MPI_Allreduce(MAXLOC|MINLOC) +
@@ -244,6 +243,11 @@ psa_status psa_group_set_seq2(psa_group* g, const char* seq2, int m);
  * device back before they return. */
 psa_status psa_search_sharded(psa_group* g, int first_offset, int last_offset, psa_result* out,
                               psa_result* shard_records);
+
+/* Host time of the group's last psa_search_sharded / psa_search_batch_sharded, microseconds from the call's entry:
+ * issue_us = until the last device's work had been enqueued (every device has a persistent launcher thread, so the
+ * devices are served side by side, not one after the other), total_us = until the call returned.  Either may be NULL. */
+psa_status psa_group_last_timing(const psa_group* g, double* issue_us, double* total_us);
 
 /* A batch of queries over the group (BASELINE.json configs[4] on several GPUs): nq queries of m characters, `stride`
  * bytes apart in host memory, dealt to the devices in contiguous blocks, each block through psa_search_batch (or

@@ -17,6 +17,9 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <memory>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -27,6 +30,9 @@
 #include <vector>
 
 #include "psa_internal.hpp"
+#ifdef PSA_EXPERIMENT
+#include "psa_debug.h"
+#endif
 
 namespace psa {
 
@@ -314,6 +320,23 @@ using psa::set_last_error;
 
 namespace {
 
+// debug library, PSA_TRACE_INIT=1: where a process's first call spends its time (tools/cold_start.py)
+#ifdef PSA_EXPERIMENT
+void init_trace(const char* stage)
+{
+    static const bool on = std::getenv("PSA_TRACE_INIT") != nullptr;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    static auto last = t0;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[psa init] %9.1f us  (+%9.1f)  %s\n", std::chrono::duration<double, std::micro>(now - t0).count(),
+                 std::chrono::duration<double, std::micro>(now - last).count(), stage);
+    last = now;
+}
+#else
+inline void init_trace(const char*) {}
+#endif
+
 // The library selects the device of the context it works on; an entry point puts the caller's current device back
 // when it returns (a host program with its own HIP / torch work on another GPU keeps launching there).
 struct DeviceScope {
@@ -501,11 +524,18 @@ struct psa_context {
     unsigned    raw_arrived = 0;
     int         raw_converters = 16;         // at most (as many as the tiles leave CUs free)
     bool        raw_force_timeout = false;   // debug library only: the tiles wait for one converter more than there is
+    bool        select_frozen = false;       // debug library only (PSA_SELECT_FROZEN): the first selection of every search runs
+    bool        select_frozen_next = false;  // against no bound at all, so the overflow -> re-selection path is taken for sure
     int         cus = 256;                   // CUs of the device
     int         seq = 0;                     // sequence number of the last search enqueued
     // device groups: the final kernel of a single search also writes its 32-byte record here (device memory)
     psa_result* record_out = nullptr;
     int         record_shard = -1;
+    // ... and the kernels that finish the queries of a batch write theirs here ([0]: the results / MAX block, [1]: the MIN
+    // block of a MIN+MAX batch; device memory, query q at + q).  batch_records_final: the batch ended without the host
+    // touching a result (no re-selection, no sequential-engine fallback), so the device blocks are what the host holds.
+    psa_result* batch_records[2] = {nullptr, nullptr};
+    bool        batch_records_final = false;
 };
 
 namespace {
@@ -814,11 +844,12 @@ psa_status ensure_stage(psa_context* c, size_t len)
 }
 
 // Both sequences of a search into the pinned staging buffer (host memcpy); the encode kernel reads them from there.
-// Sequences that lie close together in host memory (the two arrays of a ProgramData) keep their distance, so the copy is
-// one memcpy when the gap is small.
-psa_status stage_pinned_pair(psa_context* c, const char* a, size_t na, const char* b, size_t nb)
+// `one_object`: the caller knows that both lie inside ONE object (the two arrays of a ProgramData), so the bytes between
+// them may be read: they keep their distance and the copy is one memcpy when the gap is small.  Arbitrary caller
+// buffers (psa_set_sequences) are never compared or bridged: two copies.
+psa_status stage_pinned_pair(psa_context* c, const char* a, size_t na, const char* b, size_t nb, bool one_object = false)
 {
-    const bool adjacent = b >= a + na && (size_t)(b - a) <= na + 4096;
+    const bool adjacent = one_object && b >= a + na && (size_t)(b - a) <= na + 4096;
     const size_t second = adjacent ? (size_t)(b - a) : ((na + 63) & ~(size_t)63);
     const size_t len = second + nb;
     PSA_TRY(ensure_stage(c, len));
@@ -880,7 +911,9 @@ psa_status stream_pair(psa_context* c, const char* seq1, size_t limit1, bool fin
     SearchSlot& s = c->slot[0];
     const auto t_enter = std::chrono::steady_clock::now();
     PSA_TRY(ensure_ctl(c));
-    const size_t second = ((limit1 + 63) & ~(size_t)63) + 64;
+    // Seq2 starts on a 256-byte boundary at least one whole line behind Seq1's last byte: no 128-byte line holds bytes
+    // of both, so a line a Seq2 workgroup has read (before Seq1's tail was copied) never carries Seq1 bytes
+    const size_t second = ((limit1 + 255) & ~(size_t)255) + 256;
     PSA_TRY(ensure_stage(c, second + m));
     c->stage_second = second;
     const unsigned ticket = next_ticket(c);
@@ -1300,6 +1333,11 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.raw_arrivals = nullptr;
     a.raw_base = 0u;
     a.raw_converters = a.raw_expected = 0;
+    a.raw_scan_from = 0;
+#ifdef PSA_EXPERIMENT
+    a.select_frozen = c->select_frozen_next ? 1 : 0;
+    c->select_frozen_next = false;
+#endif
     const dim3 grid(p.ntiles, p.nchunks);
     if (raw) {
         if (!fused || s2 || s.s2cls != s.d_s2cls) { set_last_error("internal: a raw launch is a fused single search"); return PSA_ERR_STATE; }
@@ -1313,6 +1351,8 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
         a.tail.n1 = raw->n;
         a.tail.s1 = raw->seq1;
         a.tail.s2 = raw->seq2;
+        // what the tiles' plane builds look at (and validate) of Seq1: [base, raw_scan_from); the converters take the rest
+        a.raw_scan_from = base + 32 * ((p.ntiles - 1) * (psa::kTileStride / 32) + p.nchunks * p.class_chars + psa::kTile / 32 + 1);
         {
             if (!c->d_raw_arrivals) {
                 PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_raw_arrivals), 64));
@@ -1411,6 +1451,9 @@ psa_status launch_count_duo(psa_context* c, const unsigned* s2cls, size_t s2_str
     a.skew_ticks = (unsigned)c->duo_skew_ticks;
     a.spin_limit = c->duo_force_timeout ? 0 : (1 << 21);
     a.prio_mode = c->duo_prio_mode;
+#ifdef PSA_EXPERIMENT
+    a.select_frozen = c->select_frozen ? 1 : 0;
+#endif
     if (!deal_duo(c, a.class_chars, a.wave_lo, a.wave_hi)) { set_last_error("internal: no deal of the symbol stream"); return PSA_ERR_STATE; }
     a.bad = c->d_bad;
     for (int k = 0; k < 2; ++k) {
@@ -1481,11 +1524,16 @@ psa_status launch_filter_front(psa_context* c, SearchSlot& s, const FilterPlan& 
 
 // exact re-score of the candidates + fold into the slot's tail
 // `batch` > 0: s describes the first of `batch` consecutive pool entries (queries) re-scored by one launch
+// `record`: where the finishing kernel also writes the 32-byte record in device memory (a batch: the first query's,
+// query q at + q); default for a single search: the context's (device groups)
 psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hipStream_t stream, const TableSet& ts,
-                              int grid = psa::kRescoreGrid, int batch = 0, size_t s2_stride = 0)
+                              int grid = psa::kRescoreGrid, int batch = 0, size_t s2_stride = 0, psa_result* record = nullptr)
 {
     psa::RescoreArgs r = rescore_args(c, s, pairs, ts);
-    if (batch == 0) {
+    if (record) {
+        r.record_out = record;
+        r.record_shard = -1;
+    } else if (batch == 0) {
         r.record_out = c->record_out;
         r.record_shard = c->record_shard;
     }
@@ -1591,7 +1639,9 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     if (!out) { set_last_error("psa_create: out is NULL"); return PSA_ERR_ARG; }
     *out = nullptr;
     int count = 0;
+    init_trace("psa_create: enter");
     hipError_t e = hipGetDeviceCount(&count);
+    init_trace("psa_create: hipGetDeviceCount (HIP runtime initialised)");
     if (e != hipSuccess || count < 1) {
         set_last_error(std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0"));
         return PSA_ERR_DEVICE;
@@ -1602,15 +1652,19 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     DeviceScope device_scope;
     psa_status st = [&]() -> psa_status {
         PSA_HIP(hipSetDevice(device));
+        init_trace("psa_create: hipSetDevice");
         if (stream) c->stream = static_cast<hipStream_t>(stream);
         else {
             PSA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
             c->own_stream = true;
         }
+        init_trace("psa_create: main stream");
         if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->cus < 1) c->cus = 256;
         PSA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
         PSA_HIP(hipStreamCreateWithFlags(&c->twin, hipStreamNonBlocking));
+        init_trace("psa_create: aux + twin streams");
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_pair), sizeof(double) * psa::kRow * psa::kRow));
+        init_trace("psa_create: first hipMalloc");
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_rank), psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_sub), psa::kRow * psa::kRow));
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_clsrank), psa::kRow * psa::kRow));
@@ -1619,9 +1673,12 @@ psa_status psa_create(int device, void* stream, psa_context** out)
         PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bad), sizeof(int)));
         PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_bad), sizeof(int), hipHostMallocDefault));
         *c->h_bad = 0;
+        init_trace("psa_create: 7 more small hipMalloc + 1 hipHostMalloc");
         PSA_TRY(ensure_tails(c, 1));
         std::memset(c->h_tails, 0, sizeof(psa::SearchTail));
+        init_trace("psa_create: result tail (hipHostMalloc mapped)");
         for (auto& s : c->slot) PSA_TRY(init_slot(s));
+        init_trace("psa_create: 2 slots (8 hipMalloc, 2 hipMemset, 4 events)");
         {
             // class planes of every Seq1 symbol a over the Seq2 symbols b (group tables only):
             // word a: bit b = class(a, b) in {'*', '.'};  word 32+a: class in {':', '.'}
@@ -1637,7 +1694,9 @@ psa_status psa_create(int device, void* stream, psa_context** out)
         }
         PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
         for (auto& ev : c->ev) PSA_HIP(hipEventCreate(&ev));
+        init_trace("psa_create: symbol planes copy + memset enqueued, 4 timing events");
         PSA_HIP(hipStreamSynchronize(c->stream));
+        init_trace("psa_create: first stream synchronise");
         return PSA_OK;
     }();
     if (st != PSA_OK) { psa_destroy(c); return st; }
@@ -1662,6 +1721,7 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     if (const char* r = std::getenv("PSA_STREAM_FORCE_TIMEOUT")) c->stream_force_timeout = std::atoi(r) != 0;
     if (const char* r = std::getenv("PSA_RAW_CONVERTERS")) c->raw_converters = std::max(1, std::min(1024, std::atoi(r)));
     if (const char* r = std::getenv("PSA_RAW_FORCE_TIMEOUT")) c->raw_force_timeout = std::atoi(r) != 0;
+    if (const char* r = std::getenv("PSA_SELECT_FROZEN")) c->select_frozen = std::atoi(r) != 0;
 #endif
     *out = c;
     return PSA_OK;
@@ -1858,6 +1918,7 @@ static psa_status search_async_impl(psa_context* c, int first, int last, psa_res
         // waited for, failed or fell back can have left them dirty
         if (s.scal_dirty) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
         s.scal_dirty = true;
+        c->select_frozen_next = c->select_frozen;      // (debug library; the re-selection of settle_search runs normally)
         PSA_TRY(enqueue_filter_search(c, first, last, c->profiling));
     } else {
         PSA_TRY(launch_sequential(c, s, first, last, nullptr, nullptr, c->stream, primary_tables(c)));
@@ -1924,8 +1985,19 @@ static psa_status settle_search(psa_context* c)
 // system-scope release).  Watching that word returns the result a few microseconds before the stream's completion
 // signal would (hipStreamSynchronize: kernel end, signal, runtime wake-up); a search that takes longer than a
 // short spin falls back to it.  Everything the host touches afterwards is ordered behind the kernel by the stream.
+// How long to watch the tail word before handing the wait to the runtime: a search the cost model (use_filter) puts far
+// beyond the spin budget is not spun for at all (a 50 ms sequential-engine search would burn a core for nothing).
+static double spin_budget_us(const psa_context* c, int first, int last, int m, bool filter)
+{
+    (void)c;
+    const double pairs = (double)(last - first) * m;
+    const double expect = filter ? 36.0 + 0.002 * m + pairs / 2.6e8 : 16.0 + 0.034 * m + pairs / 8.5e6;
+    return expect <= 300.0 ? 400.0 : 0.0;
+}
+
 static bool tail_arrived(const psa_context* c, double spin_us)
 {
+    if (spin_us <= 0.0) return false;
     const volatile int* seq = &c->h_tails[0].seq;
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
@@ -1947,7 +2019,9 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));                // (a group waits for several devices' searches in turn; the retry
                                               // paths launch kernels)
-    if (c->profiling || !tail_arrived(c, 400.0)) PSA_HIP(hipStreamSynchronize(c->stream));
+    if (c->profiling ||
+        !tail_arrived(c, spin_budget_us(c, c->pending_first, c->pending_last, c->slot[0].m, c->pending_filter)))
+        PSA_HIP(hipStreamSynchronize(c->stream));
     c->pending = false;
     const psa_status st = settle_search(c);
     c->record_out = nullptr;
@@ -2016,7 +2090,7 @@ psa_status psa_search_device(psa_context* c, const void* d_seq1, int n, const vo
                                                     true, &raw);
     s.m = -1;                                      // the slot holds no encoded Seq2
     PSA_TRY(launched);
-    if (!tail_arrived(c, 400.0)) PSA_HIP(hipStreamSynchronize(c->stream));
+    if (!tail_arrived(c, spin_budget_us(c, first, last, m, true))) PSA_HIP(hipStreamSynchronize(c->stream));
     const psa::SearchTail& t = c->h_tails[0];
     if (t.seq == c->seq && t.overflow == 0 && t.bad == 0) {
         s.scal_dirty = false;                      // the search ran to its end: its last workgroup zeroed the scalars
@@ -2060,6 +2134,11 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
     if (nmodes == 2) PSA_TRY(ensure_alt_tables(c));
     const TableSet tables[2] = {primary_tables(c), alternate_tables(c)};
     psa_result* const results[2] = {results0, results1};
+    // device-side record blocks of a group batch (mode 0 = the context's own mode; the blocks are [MAX or only, MIN])
+    const bool swap_blocks = nmodes == 2 && c->tables.is_max == 0;
+    psa_result* const dev_records[2] = {c->batch_records[swap_blocks ? 1 : 0], nmodes == 2 ? c->batch_records[swap_blocks ? 0 : 1] : nullptr};
+    bool host_touched = false;
+    c->batch_records_final = false;
     PSA_TRY(ensure_tails(c, nq * nmodes));
     const unsigned char* base = static_cast<const unsigned char*>(d_queries);
     const bool filter = use_filter(c, first, last, m);
@@ -2167,7 +2246,8 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
             for (int mode = 0; mode < nmodes; ++mode) {
                 SearchSlot s = pool_view(mode, q0);
                 s.inline_select = true;
-                PSA_TRY(launch_filter_back(c, s, pairs, c->aux, tables[mode], c->batch_rescore_grid, count, (size_t)ostride));
+                PSA_TRY(launch_filter_back(c, s, pairs, c->aux, tables[mode], c->batch_rescore_grid, count, (size_t)ostride,
+                                           dev_records[mode] ? dev_records[mode] + q0 : nullptr));
             }
             c->seq = seq0 + q0 + count - 1;
         }
@@ -2182,9 +2262,11 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
             if (q == 0) c->last_kernel_queries = 1;
             PSA_HIP(hipEventRecord(s0.front_done, front));
             PSA_HIP(hipStreamWaitEvent(c->aux, s0.front_done, 0));
-            PSA_TRY(launch_filter_back(c, s0, pairs, c->aux, tables[0], c->batch_rescore_grid));
+            PSA_TRY(launch_filter_back(c, s0, pairs, c->aux, tables[0], c->batch_rescore_grid, 0, 0,
+                                       dev_records[0] ? dev_records[0] + q : nullptr));
             if (nmodes == 2) {
-                PSA_TRY(launch_filter_back(c, s1, pairs, c->aux, tables[1], c->batch_rescore_grid));
+                PSA_TRY(launch_filter_back(c, s1, pairs, c->aux, tables[1], c->batch_rescore_grid, 0, 0,
+                                           dev_records[1] ? dev_records[1] + q : nullptr));
             }
         }
     } else {
@@ -2234,6 +2316,7 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
                 // overflow against the running bound: select once more against the final one (still in the
                 // query's pool entry), with the per-query count kernel
                 SearchSlot v = pool_view(mode, q);
+                host_touched = true;
                 c->reselects += 1;
                 c->seq += 1;
                 PSA_TRY(launch_filter_front(c, v, plan, first, last, c->stream, false, tables[mode]));
@@ -2243,6 +2326,7 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
             }
             if (filter && (c->h_tails[k].overflow || stale)) {
                 SearchSlot& s = c->slot[0];
+                host_touched = true;
                 c->fallbacks += 1;
                 c->seq += 1;
                 for (auto& sl : c->slot) sl.scal_dirty = true;
@@ -2260,6 +2344,7 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
         s.m = -1;                          // the single-search Seq2 is gone
         s.d_tail = c->hd_tails;
     }
+    c->batch_records_final = pooled && dev_records[0] != nullptr && !host_touched;
     return PSA_OK;
 }
 
@@ -2347,6 +2432,8 @@ psa_status psa_scores(psa_context* c, int first, int last, double* scores, int32
     return st;
 }
 
+#ifdef PSA_EXPERIMENT
+// (test hooks: exported by libpsa_debug.so only, declared in include/psa_debug.h)
 // Diagnostic view of the filter engine's exact class counts: n_star / n_colon /
 // n_dot of every offset in [first,last).
 psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_star, uint32_t* n_colon,
@@ -2389,6 +2476,7 @@ psa_status psa_debug_counts(psa_context* c, int first, int last, uint32_t* n_sta
     }
     return PSA_OK;
 }
+#endif  // PSA_EXPERIMENT
 
 #ifdef PSA_PHASE_TIMING
 // debug build only (tools/phase_timing.py): the count kernel's phase timestamps
@@ -2398,6 +2486,7 @@ PSA_EXPORT int psa_debug_phase_ts(unsigned long long* out /* [1024][8] */)
 }
 #endif
 
+#ifdef PSA_EXPERIMENT
 // Diagnostic: the filter engine's exact re-score of arbitrary offsets
 // (find_best_mutant_offset's return value, cpu_funcs.c:299) without the filter.
 psa_status psa_debug_rescore(psa_context* c, const int32_t* offsets, int count, double* scores)
@@ -2429,6 +2518,7 @@ psa_status psa_debug_rescore(psa_context* c, const int32_t* offsets, int count, 
     for (int k = 0; k < count; ++k) scores[k] = host[(size_t)k].score;
     return PSA_OK;
 }
+#endif  // PSA_EXPERIMENT
 
 psa_status psa_set_profiling(psa_context* c, int on)
 {
@@ -2544,6 +2634,93 @@ bool load_rccl(std::string* err)
 
 }  // namespace
 
+// ---- per-device launcher threads ------------------------------------------------------------------------------
+// A group call has per-device work on the host (select the device, build the launch arguments, enqueue: ~5 us each);
+// issued from one thread the 8th shard of a 0.1 ms search started ~40 us after the first.  The group owns ONE
+// PERSISTENT THREAD PER DEVICE beyond the first (the caller's thread serves device 0): a call rings a doorbell (a
+// generation counter), every thread runs the call's job for its device, the caller waits for their "done" words.
+// A thread keeps polling the doorbell for kHotUs after its last job (back-to-back calls are picked up within a
+// microsecond), then sleeps on a condition variable (an idle group costs nothing; the first call after a pause pays
+// one wake-up).  Every thread selects its device once, when it starts.
+class GroupWorkers {
+public:
+    explicit GroupWorkers(const std::vector<int>& devices) : n_((int)devices.size()), done_((size_t)n_)
+    {
+        for (auto& d : done_) d.v.store(0u);
+        for (int i = 1; i < n_; ++i) threads_.emplace_back([this, i, dev = devices[(size_t)i]] { loop(i, dev); });
+    }
+    ~GroupWorkers()
+    {
+        stop_.store(true);
+        { std::lock_guard<std::mutex> lock(m_); }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    GroupWorkers(const GroupWorkers&) = delete;
+    GroupWorkers& operator=(const GroupWorkers&) = delete;
+
+    // job(i) for every device i of the group: i = 0 on the calling thread, the others on their own; returns when all have
+    template <typename Job>
+    void run(Job&& job)
+    {
+        std::function<void(int)> fn = std::ref(job);
+        job_ = &fn;
+        const unsigned g = gen_.load() + 1u;
+        gen_.store(g);                                   // (seq_cst, like the sleepers' count: see loop)
+        if (sleepers_.load() > 0) {
+            { std::lock_guard<std::mutex> lock(m_); }
+            cv_.notify_all();
+        }
+        job(0);
+        for (int i = 1; i < n_; ++i)
+            while (done_[(size_t)i].v.load(std::memory_order_acquire) != g) __builtin_ia32_pause();
+        job_ = nullptr;
+    }
+
+private:
+    static constexpr double kHotUs = 500.0;
+    struct alignas(64) Done { std::atomic<unsigned> v; };
+
+    void loop(int i, int device)
+    {
+        (void)hipSetDevice(device);
+        unsigned seen = 0u;
+        auto idle_since = std::chrono::steady_clock::now();
+        for (;;) {
+            unsigned g = seen;
+            for (unsigned spins = 1;; ++spins) {
+                g = gen_.load(std::memory_order_acquire);
+                if (g != seen || stop_.load(std::memory_order_relaxed)) break;
+                __builtin_ia32_pause();
+                if ((spins & 1023u) == 0u &&
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - idle_since).count() > kHotUs) {
+                    // to sleep.  The count goes up before the doorbell is looked at again (under the lock), the caller
+                    // rings before it looks at the count: one of the two sees the other (both seq_cst).
+                    std::unique_lock<std::mutex> lock(m_);
+                    sleepers_.fetch_add(1);
+                    cv_.wait(lock, [&] { return gen_.load() != seen || stop_.load(); });
+                    sleepers_.fetch_sub(1);
+                }
+            }
+            if (g == seen) return;                       // stop
+            seen = g;
+            (*job_)(i);
+            done_[(size_t)i].v.store(g, std::memory_order_release);
+            idle_since = std::chrono::steady_clock::now();
+        }
+    }
+
+    int n_;
+    std::vector<Done> done_;
+    std::vector<std::thread> threads_;
+    std::atomic<unsigned> gen_{0u};
+    std::atomic<int> sleepers_{0};
+    std::atomic<bool> stop_{false};
+    std::mutex m_;
+    std::condition_variable cv_;
+    const std::function<void(int)>* job_ = nullptr;
+};
+
 struct psa_group {
     std::vector<int>          devices;
     std::vector<psa_context*> ctx;
@@ -2561,6 +2738,9 @@ struct psa_group {
     int is_max = 1;
     bool have_weights = false;
     int n = -1, m = -1;
+    std::unique_ptr<GroupWorkers> workers;        // one launcher thread per device beyond the first
+    // the last group call: microseconds from its entry until the last device's work had been enqueued, and until it returned
+    double last_issue_us = 0.0, last_total_us = 0.0;
 };
 
 extern "C" {
@@ -2603,6 +2783,7 @@ psa_status psa_group_create_ex(const int* devices, int ndev, int exchange, psa_g
         }
         PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_send), sizeof(psa_result) * (size_t)ndev, hipHostMallocPortable));
         PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_recv), sizeof(psa_result) * (size_t)ndev, hipHostMallocPortable));
+        g->workers.reset(new GroupWorkers(g->devices));
         return PSA_OK;
     }();
     if (st != PSA_OK) { psa_group_destroy(g); return st; }
@@ -2619,6 +2800,7 @@ void psa_group_destroy(psa_group* g)
 {
     if (!g) return;
     DeviceScope device_scope;
+    g->workers.reset();                          // the launcher threads end before anything they use is freed
     for (size_t i = 0; i < g->comm.size(); ++i)
         if (g->comm[i]) (void)g_rccl.comm_destroy(g->comm[i]);
     for (size_t i = 0; i < g->d_send.size(); ++i) {
@@ -2677,13 +2859,19 @@ psa_status psa_group_set_seq1(psa_group* g, const char* seq1, int n) { return gr
 psa_status psa_group_set_seq2(psa_group* g, const char* seq2, int m) { return group_set_seq(g, seq2, m, false); }
 
 // Offsets [first,last) split over the group's devices with the reference's rank rule (psa_shard_range,
-// cpu_funcs.c:128-133), all shards searched concurrently, ONE RCCL all-gather of the 32-byte records
-// (in place of MPI_Allreduce(MAXLOC|MINLOC) + MPI_Send/Recv of the Mutant, cpu_funcs.c:71-94), then the
-// is_swapable fold (ties: lowest offset = lowest shard, like MPI_MAXLOC's lowest rank).
-// The host is not in the middle: the last kernel of every device's search writes its record straight into the
-// exchange's send buffer, the all-gather follows on the same stream, and the host waits once, for device 0's copy
-// of the gathered records.  A record tagged "look again" (candidate-list overflow, more survivors than the count
-// kernel's last workgroup takes) sends that device's search through the single-context retry path.
+// cpu_funcs.c:128-133), all shards searched concurrently, ONE exchange of the 32-byte records (RCCL all-gather in place
+// of MPI_Allreduce(MAXLOC|MINLOC) + MPI_Send/Recv of the Mutant, cpu_funcs.c:71-94), then the is_swapable fold (ties:
+// lowest offset = lowest shard, like MPI_MAXLOC's lowest rank).
+// Every device's share of the call runs on that device's launcher thread (GroupWorkers), all at once:
+//   RCCL  the search launch (its last kernel writes the record straight into the exchange's send buffer), the device's
+//         ncclAllGather on the same stream — every thread on its own communicator, the multi-thread form of a one-process
+//         communicator set — and, on device 0, the copy of the gathered records to the host and the one wait.  A record
+//         tagged "look again" (candidate-list overflow, too many survivors) or not carrying this search's tag sends that
+//         device through the single-context retry path afterwards.
+//   HOST  the search launch and the wait for that device's result tail (pinned host memory, written by the search's
+//         last kernel and polled: psa_search_wait, retry paths included); the records meet in host memory.
+// A device whose launch fails still takes part in the all-gather (with whatever its send buffer holds: the tag check
+// rejects it), so the collective cannot be left waiting for it.
 psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out, psa_result* shard_records)
 {
     if (!g || !out) { set_last_error("psa_search_sharded: NULL argument"); return PSA_ERR_ARG; }
@@ -2691,11 +2879,16 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
         set_last_error("weights, seq1 and seq2 must be set before a search");
         return PSA_ERR_STATE;
     }
+    const auto t_enter = std::chrono::steady_clock::now();
     const int ndev = (int)g->ctx.size();
     PSA_TRY(check_ready(g->ctx[0], g->m, first, last));
     DeviceScope device_scope;
     const int total = last - first;
+    const bool rccl = g->exchange == PSA_EXCHANGE_RCCL;
     std::vector<int> lo((size_t)ndev), hi((size_t)ndev), tag((size_t)ndev);
+    std::vector<psa_status> status((size_t)ndev, PSA_OK);
+    std::vector<std::string> errors((size_t)ndev);
+    std::vector<std::chrono::steady_clock::time_point> issued((size_t)ndev, t_enter);
     // whatever happens below, no context is left with a search "in flight" (an error half-way would otherwise block
     // the next call on the devices that had been started)
     struct Settle {
@@ -2715,45 +2908,66 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
         }
     } settle_on_exit{g};
     for (int i = 0; i < ndev; ++i) {
-        psa_context* c = g->ctx[i];
         psa_shard_range(total, ndev, i, &lo[i], &hi[i]);
         lo[i] += first;
         hi[i] += first;
         // what the record must carry in `shard` to count as this search's: the shard and the search's number
-        tag[i] = i | (((c->seq + 1) & 0x3fffff) << 8);
-        if (hi[i] > lo[i]) {
-            PSA_TRY(search_async_impl(c, lo[i], hi[i], g->d_send[i], tag[i]));
-        } else {
-            psa_result r;                                    // an empty shard: "nothing found" (cuda_funcs.cu:158-161)
-            r.score = g->is_max ? -INFINITY : INFINITY;
-            r.offset = -1; r.char_offset = -1; r.ch = 0; r.pairs = 0;
-            r.shard = tag[i];
-            g->h_send[i] = r;
-            c->seq += 1;
-            PSA_TRY(ensure_device(c));
-            PSA_HIP(hipMemcpyAsync(g->d_send[i], &g->h_send[i], sizeof(psa_result), hipMemcpyHostToDevice, c->stream));
-        }
+        tag[i] = i | (((g->ctx[i]->seq + 1) & 0x3fffff) << 8);
     }
-    // the exchange: every device contributes its record
-    if (g->exchange == PSA_EXCHANGE_RCCL) {
-        PSA_NCCL(g_rccl.group_start());
-        for (int i = 0; i < ndev; ++i)
-            PSA_NCCL(g_rccl.all_gather(g->d_send[i], g->d_recv[i], sizeof(psa_result), ncclChar, g->comm[i], g->ctx[i]->stream));
-        PSA_NCCL(g_rccl.group_end());
-        PSA_TRY(ensure_device(g->ctx[0]));
-        PSA_HIP(hipMemcpyAsync(g->h_recv, g->d_recv[0], sizeof(psa_result) * (size_t)ndev, hipMemcpyDeviceToHost, g->ctx[0]->stream));
-        PSA_HIP(hipStreamSynchronize(g->ctx[0]->stream));       // device 0 holds every record: every search has ended
-    } else {
-        for (int i = 0; i < ndev; ++i) {
-            PSA_TRY(ensure_device(g->ctx[i]));
-            PSA_HIP(hipMemcpyAsync(g->h_recv + i, g->d_send[i], sizeof(psa_result), hipMemcpyDeviceToHost, g->ctx[i]->stream));
-        }
-        for (int i = 0; i < ndev; ++i) {
-            PSA_TRY(ensure_device(g->ctx[i]));
-            PSA_HIP(hipStreamSynchronize(g->ctx[i]->stream));
-        }
+    auto device_job = [&](int i) {
+        psa_context* c = g->ctx[(size_t)i];
+        DeviceScope scope;                       // (the caller's thread serves device 0: its current device is put back)
+        status[(size_t)i] = [&]() -> psa_status {
+            psa_status launched = PSA_OK;
+            if (hi[i] > lo[i]) {
+                launched = search_async_impl(c, lo[i], hi[i], rccl ? g->d_send[i] : nullptr, tag[i]);
+            } else {
+                psa_result r;                                    // an empty shard: "nothing found" (cuda_funcs.cu:158-161)
+                r.score = g->is_max ? -INFINITY : INFINITY;
+                r.offset = -1; r.char_offset = -1; r.ch = 0; r.pairs = 0;
+                r.shard = tag[i];
+                c->seq += 1;
+                if (rccl) {
+                    g->h_send[i] = r;
+                    launched = ensure_device(c);
+                    if (launched == PSA_OK &&
+                        hipMemcpyAsync(g->d_send[i], &g->h_send[i], sizeof(psa_result), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                        set_last_error("psa_search_sharded: copy of an empty shard's record failed");
+                        launched = PSA_ERR_DEVICE;
+                    }
+                } else {
+                    g->h_recv[i] = r;
+                }
+            }
+            issued[(size_t)i] = std::chrono::steady_clock::now();
+            if (rccl) {
+                // (also after a failed launch: the other devices' all-gathers wait for this one)
+                PSA_TRY(ensure_device(c));
+                PSA_NCCL(g_rccl.all_gather(g->d_send[i], g->d_recv[i], sizeof(psa_result), ncclChar, g->comm[i], c->stream));
+                if (i == 0) {
+                    PSA_HIP(hipMemcpyAsync(g->h_recv, g->d_recv[0], sizeof(psa_result) * (size_t)ndev, hipMemcpyDeviceToHost, c->stream));
+                    PSA_HIP(hipStreamSynchronize(c->stream));       // device 0 holds every record: every search has ended
+                }
+            } else if (launched == PSA_OK && hi[i] > lo[i]) {
+                psa_result r;
+                PSA_TRY(psa_search_wait(c, &r));                    // this device's tail, retry paths included
+                r.shard = tag[i];
+                g->h_recv[i] = r;
+            }
+            return launched;
+        }();
+        if (status[(size_t)i] != PSA_OK) errors[(size_t)i] = psa_last_error();     // (thread-local in the launcher thread)
+    };
+    g->workers->run(device_job);
+    const auto t_done = std::chrono::steady_clock::now();
+    {
+        auto last_issue = t_enter;
+        for (const auto& t : issued) last_issue = std::max(last_issue, t);
+        g->last_issue_us = std::chrono::duration<double, std::micro>(last_issue - t_enter).count();
     }
     psa_status st = PSA_OK;
+    for (int i = 0; i < ndev && st == PSA_OK; ++i)
+        if (status[(size_t)i] != PSA_OK) { set_last_error(errors[(size_t)i]); st = status[(size_t)i]; }
     for (int i = 0; i < ndev; ++i) {
         psa_context* c = g->ctx[i];
         if (c->pending && st == PSA_OK && g->h_recv[i].shard != tag[i]) {
@@ -2773,16 +2987,31 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
         c->record_shard = -1;
         g->h_recv[i].shard = i;
     }
+    g->last_total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count();
+    (void)t_done;
     PSA_TRY(st);
     if (shard_records) std::memcpy(shard_records, g->h_recv, sizeof(psa_result) * (size_t)ndev);
     return psa_fold(g->h_recv, ndev, g->is_max, out);
 }
 
+// Host time of the last psa_search_sharded / psa_search_batch_sharded of this group, microseconds from the call's entry:
+// until the last device's work had been enqueued (the launcher threads work side by side), and until the call returned.
+psa_status psa_group_last_timing(const psa_group* g, double* issue_us, double* total_us)
+{
+    if (!g) { set_last_error("group is NULL"); return PSA_ERR_ARG; }
+    if (issue_us) *issue_us = g->last_issue_us;
+    if (total_us) *total_us = g->last_total_us;
+    return PSA_OK;
+}
+
 
 // A batch of queries over the group (BASELINE.json configs[4] on several GPUs): the queries are dealt to the devices
-// in contiguous blocks (psa_query_block: as even as possible), every device runs its block through psa_search_batch /
-// _minmax on its own host thread (the calls block), then ONE RCCL all-gather leaves all records on every device and
-// the host copies device 0's set (psa_batch_unpack puts them in query order).  results_min == NULL: one mode (the group's).
+// in contiguous blocks (psa_query_block: as even as possible); every device's launcher thread runs its block through
+// psa_search_batch / _minmax (the records also land in the device's block of the exchange's send buffer, written by the
+// kernels that finish each query) and enqueues its all-gather on the same stream; device 0's thread copies the gathered
+// blocks to the host and waits — one wait.  psa_batch_unpack puts them in query order.  A block with a query the host
+// had to finish (re-selection, sequential-engine fallback) is copied to the device again before the exchange.
+// results_min == NULL: one mode (the group's).  HOST exchange: the blocks meet in pinned host memory.
 psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, int m, size_t stride,
                                     int first, int last, psa_result* results, psa_result* results_min)
 {
@@ -2791,9 +3020,11 @@ psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, i
         return PSA_ERR_ARG;
     }
     if (!g->have_weights || g->n < 0) { set_last_error("weights and seq1 must be set before a search"); return PSA_ERR_STATE; }
+    const auto t_enter = std::chrono::steady_clock::now();
     DeviceScope device_scope;
     const int ndev = (int)g->ctx.size();
     const int nmodes = results_min ? 2 : 1;
+    const bool rccl = g->exchange == PSA_EXCHANGE_RCCL;
     const int per = psa_query_block_max(nq, ndev);          // records per device and mode in the exchange (the largest block)
     if (per > g->batch_per) {
         for (size_t i = 0; i < g->d_bsend.size(); ++i) {
@@ -2810,6 +3041,7 @@ psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, i
         for (int i = 0; i < ndev; ++i) {
             PSA_HIP(hipSetDevice(g->devices[i]));
             PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_bsend[i]), sizeof(psa_result) * 2 * (size_t)per));
+            PSA_HIP(hipMemset(g->d_bsend[i], 0, sizeof(psa_result) * 2 * (size_t)per));     // (padding entries are never unpacked)
             PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_brecv[i]), sizeof(psa_result) * 2 * (size_t)per * ndev));
         }
         PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_bsend), sizeof(psa_result) * 2 * (size_t)per * ndev, hipHostMallocPortable));
@@ -2820,55 +3052,61 @@ psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, i
     std::vector<int> lo((size_t)ndev), hi((size_t)ndev);
     std::vector<psa_status> status((size_t)ndev, PSA_OK);
     std::vector<std::string> errors((size_t)ndev);
-    std::vector<std::thread> workers;
+    std::vector<std::chrono::steady_clock::time_point> issued((size_t)ndev, t_enter);
+    const size_t block = sizeof(psa_result) * 2 * (size_t)per;
     psa_result none;
     none.score = 0.0; none.offset = -1; none.char_offset = -1; none.ch = 0; none.shard = -1; none.pairs = 0;
     for (int i = 0; i < ndev; ++i) {
         psa_query_block(nq, ndev, i, &lo[i], &hi[i]);
-        psa_result* mine = g->h_bsend + (size_t)i * 2 * per;
-        for (int k = 0; k < 2 * per; ++k) mine[k] = none;
-        const int count = hi[i] - lo[i];
-        if (count <= 0) continue;
-        if (count > per) { set_last_error("internal: a query block exceeds the exchange block"); return PSA_ERR_STATE; }
-        workers.emplace_back([=, &status, &errors]() {
-            const char* q0 = queries + (size_t)lo[i] * stride;
-            psa_status st;
-            if (nmodes == 2) {
-                // the group's mode first: results / results_min are MAX / MIN
-                psa_result* mx = mine;
-                psa_result* mn = mine + per;
-                st = psa_search_batch_minmax(g->ctx[i], q0, count, m, stride, first, last, mx, mn);
-            } else {
-                st = psa_search_batch(g->ctx[i], q0, count, m, stride, first, last, mine);
+        if (hi[i] - lo[i] > per) { set_last_error("internal: a query block exceeds the exchange block"); return PSA_ERR_STATE; }
+    }
+    auto device_job = [&](int i) {
+        psa_context* c = g->ctx[(size_t)i];
+        DeviceScope scope;
+        status[(size_t)i] = [&]() -> psa_status {
+            psa_result* mine = g->h_bsend + (size_t)i * 2 * per;
+            for (int k = 0; k < 2 * per; ++k) mine[k] = none;
+            const int count = hi[i] - lo[i];
+            psa_status st = PSA_OK;
+            bool on_device = false;                // the kernels have written this block's records to d_bsend[i]
+            if (count > 0) {
+                const char* q0 = queries + (size_t)lo[i] * stride;
+                // (the group's mode first: results / results_min are MAX / MIN)
+                c->batch_records[0] = rccl ? g->d_bsend[i] : nullptr;
+                c->batch_records[1] = rccl && nmodes == 2 ? g->d_bsend[i] + per : nullptr;
+                c->batch_records_final = false;
+                if (nmodes == 2) st = psa_search_batch_minmax(c, q0, count, m, stride, first, last, mine, mine + per);
+                else st = psa_search_batch(c, q0, count, m, stride, first, last, mine);
+                on_device = rccl && c->batch_records_final;
+                c->batch_records[0] = c->batch_records[1] = nullptr;
             }
-            status[i] = st;
-            if (st != PSA_OK) errors[i] = psa_last_error();             // (thread-local in the worker)
-        });
+            issued[(size_t)i] = std::chrono::steady_clock::now();
+            if (rccl) {
+                // (a failed batch still takes part in the exchange: the other devices' all-gathers wait for this one)
+                PSA_TRY(ensure_device(c));
+                if (!on_device)
+                    PSA_HIP(hipMemcpyAsync(g->d_bsend[i], mine, block, hipMemcpyHostToDevice, c->stream));
+                PSA_NCCL(g_rccl.all_gather(g->d_bsend[i], g->d_brecv[i], block, ncclChar, g->comm[i], c->stream));
+                if (i == 0) {
+                    PSA_HIP(hipMemcpyAsync(g->h_brecv, g->d_brecv[0], block * (size_t)ndev, hipMemcpyDeviceToHost, c->stream));
+                    PSA_HIP(hipStreamSynchronize(c->stream));       // device 0 holds every block: every batch has ended
+                }
+            }
+            return st;
+        }();
+        if (status[(size_t)i] != PSA_OK) errors[(size_t)i] = psa_last_error();     // (thread-local in the launcher thread)
+    };
+    g->workers->run(device_job);
+    {
+        auto last_issue = t_enter;
+        for (const auto& t : issued) last_issue = std::max(last_issue, t);
+        g->last_issue_us = std::chrono::duration<double, std::micro>(last_issue - t_enter).count();
+        g->last_total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count();
     }
-    for (auto& w : workers) w.join();
     for (int i = 0; i < ndev; ++i)
-        if (status[i] != PSA_OK) { set_last_error(errors[i]); return status[i]; }
-    // the exchange: one all-gather of the per-device blocks
-    const size_t block = sizeof(psa_result) * 2 * (size_t)per;
-    const psa_result* gathered = g->h_bsend;                // host exchange: the blocks already lie side by side
-    if (g->exchange == PSA_EXCHANGE_RCCL) {
-        for (int i = 0; i < ndev; ++i) {
-            PSA_HIP(hipSetDevice(g->devices[i]));
-            PSA_HIP(hipMemcpyAsync(g->d_bsend[i], g->h_bsend + (size_t)i * 2 * per, block, hipMemcpyHostToDevice, g->ctx[i]->stream));
-        }
-        PSA_NCCL(g_rccl.group_start());
-        for (int i = 0; i < ndev; ++i)
-            PSA_NCCL(g_rccl.all_gather(g->d_bsend[i], g->d_brecv[i], block, ncclChar, g->comm[i], g->ctx[i]->stream));
-        PSA_NCCL(g_rccl.group_end());
-        PSA_HIP(hipSetDevice(g->devices[0]));
-        PSA_HIP(hipMemcpyAsync(g->h_brecv, g->d_brecv[0], block * (size_t)ndev, hipMemcpyDeviceToHost, g->ctx[0]->stream));
-        for (int i = 0; i < ndev; ++i) {
-            PSA_HIP(hipSetDevice(g->devices[i]));
-            PSA_HIP(hipStreamSynchronize(g->ctx[i]->stream));
-        }
-        gathered = g->h_brecv;
-    }
-    return psa_batch_unpack(gathered, nq, ndev, results, results_min);
+        if (status[(size_t)i] != PSA_OK) { set_last_error(errors[(size_t)i]); return status[(size_t)i]; }
+    // host exchange: the blocks already lie side by side in pinned host memory
+    return psa_batch_unpack(rccl ? g->h_brecv : g->h_bsend, nq, ndev, results, results_min);
 }
 }  // extern "C"
 
@@ -2897,6 +3135,7 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
                               Mutant* returned_mutant, int first_offset, int last_offset)
 {
     std::lock_guard<std::mutex> lock(g_legacy_mutex);
+    init_trace("gpu_run_program: enter");
     const char* base = static_cast<const char*>(cpu_data);
     int is_max;
     double weights[4];
@@ -2974,7 +3213,9 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
             if (psa_create(device, nullptr, &g_legacy_ctx) != PSA_OK) legacy_die("Failed to initialise the device context");
         }
         psa_context* c = g_legacy_ctx;
+        init_trace("gpu_run_program: context ready");
         if (psa_set_weights(c, weights, is_max) != PSA_OK) legacy_die("Failed to build the score tables");
+        init_trace("gpu_run_program: weights (tables built, 5 copies, synchronise)");
         // The two arrays of a ProgramData lie side by side: one host memcpy into pinned staging (the reference copies the
         // whole struct, cuda_funcs.cu:50), an encode launch that reads it over PCIe, one search launch; the alphabet flag
         // comes back with the result tail.
@@ -2986,17 +3227,20 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
             if (ensure_device(c) != PSA_OK || stream_pair(c, seq1, seq1_cap, true, seq2, (size_t)m, &n) != PSA_OK)
                 legacy_die("Failed to copy data from host to device");
             if ((size_t)n >= seq1_cap) no_nul();
+            init_trace("gpu_run_program: streamed transfer enqueued (first kernel launch: code object load)");
             searched = psa_search(c, first_offset, last_offset, &r) == PSA_OK;
+            init_trace("gpu_run_program: search returned");
             if (!searched && !c->stream_gave_up) legacy_die("Failed to run the search");
             c->stream_gave_up = false;       // (gave up: the host stalled mid-copy; once more the plain way)
         }
         if (!searched) {
-            if (n < 1 || ensure_device(c) != PSA_OK || stage_pinned_pair(c, seq1, (size_t)n, seq2, (size_t)m) != PSA_OK ||
+            if (n < 1 || ensure_device(c) != PSA_OK || stage_pinned_pair(c, seq1, (size_t)n, seq2, (size_t)m, true) != PSA_OK ||
                 encode_pair(c, c->hd_stage, n, c->hd_stage + c->stage_second, m) != PSA_OK)
                 legacy_die("Failed to copy data from host to device");
             if (psa_search(c, first_offset, last_offset, &r) != PSA_OK) legacy_die("Failed to run the search");
         }
     }
+    init_trace("gpu_run_program: done");
     if (r.offset < 0 || r.ch == 0) return none;   // cuda_funcs.cu:143-144
     returned_mutant->offset = r.offset;
     returned_mutant->char_offset = r.char_offset;

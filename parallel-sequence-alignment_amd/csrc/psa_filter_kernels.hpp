@@ -1812,6 +1812,13 @@ struct CountArgs {
     unsigned    raw_base;
     int         raw_converters;
     int         raw_expected;         // = raw_converters (the debug library can ask for one more: the wait then gives up)
+    // The tiles validate the Seq1 bytes of their own windows, [base, raw_scan_from) all in all.  psa_search_device promises
+    // the errors of psa_set_sequences_device + psa_search, which encodes all n1 bytes: the converters look at the rest,
+    // [0, base) and [raw_scan_from, n1) — nothing for a search over every offset.
+    int         raw_scan_from;
+#ifdef PSA_EXPERIMENT
+    int         select_frozen;        // debug library: the tiles select against "no bound at all" (forces the overflow path)
+#endif
     RescoreArgs tail;
 };
 
@@ -1876,6 +1883,34 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
                 }
                 __hip_atomic_store(a.classes_w + j, code << kRowShift, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+        }
+        // Seq1 outside the tiles' windows (a search of a sub-range): 16 bytes per thread and step, all converters together
+        {
+            const int lo_units = a.base >> 4;                                   // [0, base): base is a multiple of 32
+            const int hi_units = a.raw_scan_from < a.n1 ? (a.n1 - a.raw_scan_from + 15) >> 4 : 0;
+            const bool aligned = ((reinterpret_cast<size_t>(a.raw1) | (size_t)a.raw_scan_from) & 15) == 0;
+            bool any_bad = false;
+            for (int u = (int)blockIdx.x * WAVES * 64 + tid; u < lo_units + hi_units; u += conv_wgs * WAVES * 64) {
+                const int p0 = u < lo_units ? u << 4 : a.raw_scan_from + ((u - lo_units) << 4);
+                unsigned w[4];
+                if (aligned && p0 + 16 <= a.n1) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(a.raw1 + p0);
+                    w[0] = q.x; w[1] = q.y; w[2] = q.z; w[3] = q.w;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        w[q] = 0x41414141u;                                     // behind the end: 'A'
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (p0 + 4 * q + r < a.n1) w[q] = (w[q] & ~(0xffu << (8 * r))) | ((unsigned)a.raw1[p0 + 4 * q + r] << (8 * r));
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) any_bad |= ascii_code((w[q] >> (8 * r)) & 0xffu) == (unsigned)kCodePad;
+            }
+            if (any_bad) atomicOr(a.bad, 1);                                    // a character of Seq1 outside [A-Z-]
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // every wave's stores have been performed,
         __syncthreads();                                            // then ONE lane's arrival
@@ -2113,7 +2148,10 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     __syncthreads();
     for (int mode = 0; mode < a.nmodes; ++mode) {
         const CountArgs::CountSelect& sel = a.sel[mode];
-        const double need = key_order(s_best[mode][WAVES]);
+        double need = key_order(s_best[mode][WAVES]);
+#ifdef PSA_EXPERIMENT
+        if (a.select_frozen) need = -1.7976931348623157e308;    // every real offset is a candidate (not the -inf of the others)
+#endif
 #pragma unroll
         for (int e = 0; e < kPer; ++e)
             if (up[mode][e] >= need) {
@@ -2184,6 +2222,9 @@ struct DuoArgs {
     int spin_limit;       // polls a group barrier waits before it gives up (debug library: 0 forces the give-up path)
     unsigned short wave_lo[8], wave_hi[8];   // the shares of a group's eight waves of a query's symbol stream, in rounds
     int prio_mode;        // 0: the younger waves of a group at the higher priority (product); 1-3: experiments
+#ifdef PSA_EXPERIMENT
+    int select_frozen;    // debug library: select against "no bound at all" (forces the overflow path)
+#endif
     int* bad;             // |= 4 if a group barrier timed out (never expected): the host redoes the batch without this kernel
     struct Select {
         char*   scalars;      // search scalars of the launch's first query (kScalStride apart)
@@ -2343,7 +2384,10 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
                 s_best[group][kDuoGroupWaves] = old > key ? old : key;
             }
             duo_barrier(bar, bar_target, lane, a.bad, a.spin_limit);
-            const double need = key_order(s_best[group][kDuoGroupWaves]);
+            double need = key_order(s_best[group][kDuoGroupWaves]);
+#ifdef PSA_EXPERIMENT
+            if (a.select_frozen) need = -1.7976931348623157e308;
+#endif
 #pragma unroll
             for (int e = 0; e < kDuoPer; ++e)
                 if (up[e] >= need) {
@@ -2386,6 +2430,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
         a.done = reinterpret_cast<int*>(reinterpret_cast<char*>(a.done) + q * kScalStride);
         a.out += q;
         a.seq += (int)q;
+        if (a.record_out) a.record_out += q;
     }
 #ifdef PSA_PHASE_TIMING
 #define PSA_RPHASE(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_phase_ts[1000][k] = wall_clock64(); } while (0)

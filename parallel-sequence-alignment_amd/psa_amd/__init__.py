@@ -37,13 +37,15 @@ EXPORTED_SYMBOLS = (
     "psa_raw_retry_count", "psa_scores", "psa_streamed_count", "psa_stream_retry_count",
     "psa_search_batch", "psa_search_batch_device",
     "psa_search_batch_minmax", "psa_search_batch_minmax_device",
-    "psa_debug_counts", "psa_fallback_count", "psa_reselect_count", "psa_unfused_count", "psa_duo_retry_count", "psa_debug_rescore",
+    "psa_fallback_count", "psa_reselect_count", "psa_unfused_count", "psa_duo_retry_count",
     "psa_group_create", "psa_group_create_ex", "psa_group_destroy", "psa_group_size", "psa_group_set_weights",
-    "psa_group_set_seq1", "psa_group_set_seq2", "psa_search_sharded", "psa_search_batch_sharded",
+    "psa_group_set_seq1", "psa_group_set_seq2", "psa_search_sharded", "psa_search_batch_sharded", "psa_group_last_timing",
     "psa_fold", "psa_shard_range", "psa_query_block", "psa_query_block_max", "psa_batch_unpack", "psa_build_tables",
     "psa_set_profiling", "psa_last_timing", "psa_profile_totals", "psa_last_kernel_queries",
     "psa_generate_sequence", "psa_last_error", "psa_version",
 )
+# test hooks of libpsa_debug.so only (include/psa_debug.h; the product library does not export them)
+DEBUG_SYMBOLS = ("psa_debug_counts", "psa_debug_rescore")
 
 
 class PsaError(RuntimeError):
@@ -100,12 +102,13 @@ def _load() -> C.CDLL:
     lib.psa_search_batch_device.argtypes = [vp, vp, i, i, C.c_size_t, i, i, C.POINTER(Result)]
     lib.psa_search_batch_minmax.argtypes = [vp, C.c_char_p, i, i, C.c_size_t, i, i, C.POINTER(Result), C.POINTER(Result)]
     lib.psa_search_batch_minmax_device.argtypes = [vp, vp, i, i, C.c_size_t, i, i, C.POINTER(Result), C.POINTER(Result)]
-    lib.psa_debug_counts.argtypes = [vp, i, i, vp, vp, vp]
+    if hasattr(lib, "psa_debug_counts"):                   # libpsa_debug.so
+        lib.psa_debug_counts.argtypes = [vp, i, i, vp, vp, vp]
+        lib.psa_debug_rescore.argtypes = [vp, vp, i, vp]
     lib.psa_fallback_count.argtypes = [vp]
     lib.psa_reselect_count.argtypes = [vp]
     lib.psa_duo_retry_count.argtypes = [vp]
     lib.psa_unfused_count.argtypes = [vp]
-    lib.psa_debug_rescore.argtypes = [vp, vp, i, vp]
     lib.psa_group_create.argtypes = [C.POINTER(i), i, C.POINTER(vp)]
     lib.psa_group_create_ex.argtypes = [C.POINTER(i), i, i, C.POINTER(vp)]
     lib.psa_group_destroy.argtypes = [vp]
@@ -116,6 +119,7 @@ def _load() -> C.CDLL:
     lib.psa_group_set_seq2.argtypes = [vp, C.c_char_p, i]
     lib.psa_search_sharded.argtypes = [vp, i, i, C.POINTER(Result), C.POINTER(Result)]
     lib.psa_search_batch_sharded.argtypes = [vp, C.c_char_p, i, i, C.c_size_t, i, i, C.POINTER(Result), C.POINTER(Result)]
+    lib.psa_group_last_timing.argtypes = [vp, dp, dp]
     lib.psa_fold.argtypes = [C.POINTER(Result), i, i, C.POINTER(Result)]
     lib.psa_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.psa_shard_range.restype = None
@@ -376,7 +380,9 @@ class Context:
         return s, ci, ch
 
     def debug_counts(self, first: Optional[int] = None, last: Optional[int] = None):
-        """Filter engine's exact (n_star, n_colon, n_dot) per offset."""
+        """Filter engine's exact (n_star, n_colon, n_dot) per offset (libpsa_debug.so only)."""
+        if not hasattr(lib, "psa_debug_counts"):
+            raise PsaError(PSA_ERR_STATE, "psa_debug_counts is a test hook of libpsa_debug.so (PSA_AMD_LIB), not of libpsa_amd.so")
         first = 0 if first is None else first
         last = self.total_offsets() if last is None else last
         span = last - first
@@ -385,7 +391,9 @@ class Context:
         return a, b, c
 
     def debug_rescore(self, offsets) -> np.ndarray:
-        """Exact re-score of the given offsets (filter engine's rescore kernel)."""
+        """Exact re-score of the given offsets (filter engine's rescore kernel; libpsa_debug.so only)."""
+        if not hasattr(lib, "psa_debug_rescore"):
+            raise PsaError(PSA_ERR_STATE, "psa_debug_rescore is a test hook of libpsa_debug.so (PSA_AMD_LIB), not of libpsa_amd.so")
         offs = np.ascontiguousarray(offsets, np.int32)
         out = np.empty(len(offs), np.float64)
         _check(lib.psa_debug_rescore(self._h, offs.ctypes.data, len(offs), out.ctypes.data))
@@ -477,6 +485,12 @@ class Group:
         _check(lib.psa_search_batch_sharded(self._h, b"".join(queries), len(queries), m, m, first, last, hi,
                                             lo if minmax else None))
         return (list(hi), list(lo)) if minmax else list(hi)
+
+    def last_timing(self):
+        """(issue_us, total_us) of the last group call: host time until every device's work was enqueued / until it returned."""
+        a, b = C.c_double(), C.c_double()
+        _check(lib.psa_group_last_timing(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def search(self, first: Optional[int] = None, last: Optional[int] = None):
         """-> (folded Result, [per-device Result])"""

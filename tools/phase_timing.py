@@ -18,19 +18,37 @@ m = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 last = int(sys.argv[4]) if len(sys.argv) > 4 else n - m + 1
 raw = os.environ.get("PHASE_RAW") == "1"          # the one-shot search from raw ASCII (psa_count_kernel<16, raw>)
+# PHASE_ALPHABET=ACGT (or any letters; a trailing :w1,w2,.. gives relative frequencies): a low-entropy input instead of
+# uniform A..Z;  PHASE_MIN=1: a minimum search
+alphabet = os.environ.get("PHASE_ALPHABET", "")
+is_max = os.environ.get("PHASE_MIN") != "1"
+
+
+def make(seed, length):
+    if not alphabet:
+        return psa_amd.generate_sequence_np(seed, length)
+    letters, _, freq = alphabet.partition(":")
+    p = None
+    if freq:
+        p = np.array([float(x) for x in freq.split(",")])
+        p /= p.sum()
+    return np.random.default_rng(seed).choice(np.frombuffer(letters.encode(), np.uint8), length, p=p)
+
+
+seq1_np, seq2_np = make(1002, n), make(2002, m)
 ctx = psa_amd.Context()
-ctx.set_weights([1.5, 2.6, 0.3, 0.2], True)
-ctx.set_seq1(psa_amd.generate_sequence(1002, n))
-ctx.set_seq2(psa_amd.generate_sequence(2002, m))
+ctx.set_weights([1.5, 2.6, 0.3, 0.2], is_max)
+ctx.set_seq1(seq1_np.tobytes())
+ctx.set_seq2(seq2_np.tobytes())
 if raw:
-    d1 = torch.from_numpy(psa_amd.generate_sequence_np(1002, n)).cuda()
-    d2 = torch.from_numpy(psa_amd.generate_sequence_np(2002, m)).cuda()
+    d1 = torch.from_numpy(seq1_np).cuda()
+    d2 = torch.from_numpy(seq2_np).cuda()
     torch.cuda.synchronize()
 for _ in range(3):
     r = ctx.search_device(d1.data_ptr(), n, d2.data_ptr(), m, first, last) if raw else ctx.search(first, last)
 if raw:
-    ctx.set_seq1(psa_amd.generate_sequence(1002, n))
-    ctx.set_seq2(psa_amd.generate_sequence(2002, m))
+    ctx.set_seq1(seq1_np.tobytes())
+    ctx.set_seq2(seq2_np.tobytes())
 lib = psa_amd._lib if hasattr(psa_amd, "_lib") else psa_amd.lib
 buf = (C.c_ulonglong * (1024 * 8))()
 lib.psa_debug_phase_ts.restype = C.c_int
