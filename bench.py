@@ -712,7 +712,7 @@ def main():
                     "golden": "tests/golden/synthetic_golden.json c3_max / c3_min (CPU oracle, 48 s each)"}
 
     # ---- extras (one GPU, rank 0): the other engine, the offset shard emulated, a low-entropy input -----------
-    sequential = shard_emulation = low_entropy = None
+    sequential = shard_emulation = low_entropy = low_protein = None
     if extras and (n, m) == (1_000_000, 10_000):
         # the literal north_star kernel: lane per offset, fp64 sum in the reference's order for EVERY offset
         ctx.set_engine(psa.ENGINE_SEQUENTIAL)
@@ -747,24 +747,36 @@ def main():
             "note": "rank 0's shard of an N-way split timed on ONE GPU (N = 1, 2, 4, 8), exchange not included: an "
                     "emulation, not a scaling measurement.  A single 0.1 ms search is dominated by fixed costs (launch, plane "
                     "build, epilogue, exact re-score) and cannot scale near-linearly; searches in flight do"}
-        # A plausible low-entropy workload: four-letter alphabet (far more near-ties than uniform A..Z)
-        rng = np.random.default_rng(4)
-        acgt = np.frombuffer(b"ACGT", np.uint8)
-        a1 = torch.from_numpy(rng.choice(acgt, n)).to(device)
-        a2 = torch.from_numpy(rng.choice(acgt, m)).to(device)
-        low_entropy = {}
+        # Plausible low-entropy workloads: a four-letter alphabet (far more near-ties than uniform A..Z, and a running sum
+        # that hovers around zero) and the 20 amino-acid letters with their natural frequencies (the draws of
+        # tests/golden/make_golden.py --acgt / --protein, whose oracle answers the GPU tests compare with)
+        uniform_us = {}
         for is_max in (True, False):
             ctx.set_weights(WEIGHTS, is_max)
-            before = (ctx.fallback_count(), ctx.reselect_count(), ctx.unfused_count())
-            ctx.set_sequences_device(a1.data_ptr(), n, a2.data_ptr(), m)
-            r = ctx.search(0, total)
-            us = median_us(lambda: ctx.search(0, total), sync, reps=8, warm=1)
-            after = (ctx.fallback_count(), ctx.reselect_count(), ctx.unfused_count())
-            low_entropy["max" if is_max else "min"] = {
-                "search_only_us": us, "offset": r.offset, "score": r.score,
-                "fallbacks": after[0] - before[0], "reselects": after[1] - before[1], "second_launches": after[2] - before[2]}
-        low_entropy["note"] = ("|Seq1|=1M, |Seq2|=10k uniform over ACGT, README weights: same engine, counters = what the "
-                               "10 searches of the probe needed (tests/test_gpu_parity.py checks the answers against the oracle)")
+            ctx.set_sequences_device(p1, n, p2, m)
+            ctx.search(0, total)
+            uniform_us[is_max] = median_us(lambda: ctx.search(0, total), sync, reps=8, warm=1)
+        low_entropy, low_protein = {}, {}
+        prot = np.asarray([7.8, 5.1, 4.5, 5.4, 1.9, 4.3, 6.3, 7.4, 2.2, 5.1, 9.1, 5.7, 2.2, 3.9, 5.2, 7.1, 5.8, 1.3, 3.2, 6.4])
+        for dest, seed, letters, freq in ((low_entropy, 4, b"ACGT", None), (low_protein, 5, b"ARNDCQEGHILKMFPSTWYV", prot / prot.sum())):
+            rng = np.random.default_rng(seed)
+            ab = np.frombuffer(letters, np.uint8)
+            a1 = torch.from_numpy(rng.choice(ab, n, p=freq)).to(device)
+            a2 = torch.from_numpy(rng.choice(ab, m, p=freq)).to(device)
+            for is_max in (True, False):
+                ctx.set_weights(WEIGHTS, is_max)
+                before = (ctx.fallback_count(), ctx.reselect_count(), ctx.unfused_count())
+                ctx.set_sequences_device(a1.data_ptr(), n, a2.data_ptr(), m)
+                r = ctx.search(0, total)
+                us = median_us(lambda: ctx.search(0, total), sync, reps=8, warm=1)
+                after = (ctx.fallback_count(), ctx.reselect_count(), ctx.unfused_count())
+                dest["max" if is_max else "min"] = {
+                    "search_only_us": us, "ratio_to_uniform_a_z": us / uniform_us[is_max], "offset": r.offset, "score": r.score,
+                    "fallbacks": after[0] - before[0], "reselects": after[1] - before[1], "second_launches": after[2] - before[2]}
+        low_entropy["note"] = ("|Seq1|=1M, |Seq2|=10k uniform over ACGT, README weights: same engine, counters = what the 10 searches "
+                               "of the probe needed; ratio = to the same probe on the uniform A..Z headline input "
+                               "(tests/test_gpu_parity.py checks the answers against committed oracle goldens)")
+        low_protein["note"] = "the same with the 20 amino-acid letters at their natural frequencies (Robinson & Robinson)"
         ctx.set_weights(WEIGHTS, True)
 
     # ---- SURVEY.md 8(d)'s other timed region: process start -> output.txt closed, the drop-in program on configs[2]
@@ -911,6 +923,7 @@ def main():
         line["shard_emulation"] = shard_emulation
     if low_entropy:
         line["low_entropy_acgt"] = low_entropy
+        line["low_entropy_protein"] = low_protein
     if drop_in:
         line["drop_in_program"] = drop_in
     if offset_shard:

@@ -442,6 +442,16 @@ struct psa_context {
     bool rescore_pad = true;
     bool        own_stream = false;
 
+    // Everything of fixed size lives in TWO allocations made by psa_create (round 4; before: ~25 hipMalloc / hipHostMalloc
+    // calls and 3 streams, of which a single gpu_run_program needs one): a device arena — score tables of both modes,
+    // symbol planes, alphabet flag, control words, the slots' search scalars, candidate lists and records — zeroed by
+    // one fill, and a pinned host-coherent arena (control word, the single search's result tail, the flag's host copy).
+    // The second and third stream, the inter-stream events and the timing events are created by the first batch /
+    // psa_set_profiling(1) (ensure_batch_objects, ensure_timing_events).
+    unsigned char* d_arena = nullptr;
+    unsigned char* h_arena = nullptr;     // pinned, mapped, coherent
+    bool        tails_in_arena = true;
+
     psa::Tables tables;
     bool        have_weights = false;
     int         n = -1;
@@ -595,12 +605,6 @@ psa_status ensure_alt_tables(psa_context* c)
         set_last_error(err);
         return PSA_ERR_ARG;
     }
-    if (!c->d_alt_rank) {
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_alt_rank), psa::kRow * psa::kRow));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_alt_sub), psa::kRow * psa::kRow));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_alt_clsrank), psa::kRow * psa::kRow));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_alt_delta), sizeof(double) * psa::kMaxRanks));
-    }
     PSA_TRY(upload_mode_tables(c, c->alt_tables, c->d_alt_rank, c->d_alt_sub, c->d_alt_delta, c->d_alt_clsrank));
     c->have_alt = true;
     return PSA_OK;
@@ -645,13 +649,9 @@ psa_status report_bad(psa_context* c)
 // workgroups' arrival counter.
 psa_status ensure_ctl(psa_context* c)
 {
-    if (c->h_ctl) return PSA_OK;
-    PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_ctl), 128, hipHostMallocMapped | hipHostMallocCoherent));
-    std::memset(c->h_ctl, 0, 128);
-    PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&c->hd_ctl), c->h_ctl, 0));
-    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_ctl), 128));
-    PSA_HIP(hipMemsetAsync(c->d_ctl, 0, 128, c->stream));
-    return PSA_OK;
+    if (c->h_ctl) return PSA_OK;                  // (psa_create carves them out of the arenas)
+    set_last_error("internal: no control words");
+    return PSA_ERR_STATE;
 }
 
 unsigned next_ticket(psa_context* c)
@@ -969,7 +969,8 @@ psa_status stream_pair(psa_context* c, const char* seq1, size_t limit1, bool fin
 psa_status ensure_tails(psa_context* c, int count)
 {
     if (count <= c->tails_cap) return PSA_OK;
-    if (c->h_tails) PSA_HIP(hipHostFree(c->h_tails));
+    if (c->h_tails && !c->tails_in_arena) PSA_HIP(hipHostFree(c->h_tails));   // (the first tail is part of the pinned arena)
+    c->tails_in_arena = false;
     c->h_tails = nullptr;
     c->tails_cap = 0;
     PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_tails), sizeof(psa::SearchTail) * (size_t)count,
@@ -1201,7 +1202,7 @@ psa::RescoreArgs rescore_args(const psa_context* c, const SearchSlot& s, long lo
         constexpr bool walk_only = false;
 #endif
         // |sequential fp64 prefix sum - exact prefix sum| <= (k-1) u sum|p_i| / (1 - k u) <= m u m wmax; doubled, and the
-        // order-free evaluation certified_sum compares with adds a few roundings of its own (far inside the factor)
+        // order-free evaluation the certificate compares with adds a few roundings of its own (far inside the factor)
         double wmax = 0.0;
         for (int i = 0; i < 4; ++i) wmax = std::fmax(wmax, std::fabs(r.class_value[i]));
         r.walk_slack = 2.1 * ((double)s.m + 32.0) * 1.1102230246251565e-16 * ((double)s.m * wmax);
@@ -1354,11 +1355,6 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
         // what the tiles' plane builds look at (and validate) of Seq1: [base, raw_scan_from); the converters take the rest
         a.raw_scan_from = base + 32 * ((p.ntiles - 1) * (psa::kTileStride / 32) + p.nchunks * p.class_chars + psa::kTile / 32 + 1);
         {
-            if (!c->d_raw_arrivals) {
-                PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_raw_arrivals), 64));
-                PSA_HIP(hipMemsetAsync(c->d_raw_arrivals, 0, 64, stream));
-                c->raw_arrived = 0u;
-            }
             // converter workgroups in front of the tiles: on the CUs the tiles leave free (at most 16), at least as many
             // as keep a thread's share within kRawPerThread positions
             const long long tiles = (long long)p.ntiles * p.nchunks;
@@ -1602,15 +1598,25 @@ psa_status ensure_pool(psa_context* c, int nq)
     return PSA_OK;
 }
 
-psa_status init_slot(SearchSlot& s)
+// The second and third stream (re-scores of a batch, alternate count launches) and the events between the streams:
+// only batches use them, so the first batch creates them (a stream costs ~8 ms to create on this runtime — a fresh
+// process that makes one gpu_run_program call does not pay for two it never uses).
+psa_status ensure_batch_objects(psa_context* c)
 {
-    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_scal), sizeof(Scalars)));
-    PSA_HIP(hipMemset(s.d_scal, 0, sizeof(Scalars)));
-    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_cand), sizeof(int) * kCandCap));
-    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_cand_upper), sizeof(double) * kCandCap));
-    PSA_HIP(hipMalloc(reinterpret_cast<void**>(&s.d_rec), sizeof(psa::CandRec) * kCandCap));
-    PSA_HIP(hipEventCreateWithFlags(&s.front_done, hipEventDisableTiming));
-    PSA_HIP(hipEventCreateWithFlags(&s.back_done, hipEventDisableTiming));
+    if (c->aux) return PSA_OK;
+    PSA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    PSA_HIP(hipStreamCreateWithFlags(&c->twin, hipStreamNonBlocking));
+    for (auto& s : c->slot) {
+        PSA_HIP(hipEventCreateWithFlags(&s.front_done, hipEventDisableTiming));
+        PSA_HIP(hipEventCreateWithFlags(&s.back_done, hipEventDisableTiming));
+    }
+    return PSA_OK;
+}
+
+psa_status ensure_timing_events(psa_context* c)
+{
+    for (auto& ev : c->ev)
+        if (!ev) PSA_HIP(hipEventCreate(&ev));
     return PSA_OK;
 }
 
@@ -1622,11 +1628,7 @@ void free_slot(SearchSlot& s)
     (void)hipFree(s.d_blocks);
     (void)hipFree(s.d_partial);
     (void)hipFree(s.d_arrivals);
-    (void)hipFree(s.d_scal);
-    (void)hipFree(s.d_cand);
-    (void)hipFree(s.d_cand_upper);
-    (void)hipFree(s.d_rec);
-    if (s.front_done) (void)hipEventDestroy(s.front_done);
+    if (s.front_done) (void)hipEventDestroy(s.front_done);       // (scalars, candidate lists, records: the device arena)
     if (s.back_done) (void)hipEventDestroy(s.back_done);
 }
 
@@ -1654,31 +1656,79 @@ psa_status psa_create(int device, void* stream, psa_context** out)
         PSA_HIP(hipSetDevice(device));
         init_trace("psa_create: hipSetDevice");
         if (stream) c->stream = static_cast<hipStream_t>(stream);
+#ifdef PSA_EXPERIMENT
+        else if (const char* how = std::getenv("PSA_MAIN_STREAM")) {      // cold-start experiment: what a created stream costs
+            c->stream = std::strcmp(how, "perthread") == 0 ? hipStreamPerThread : nullptr;
+            init_trace(std::strcmp(how, "perthread") == 0 ? "psa_create: hipStreamPerThread" : "psa_create: the null stream");
+        }
+#endif
         else {
             PSA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
             c->own_stream = true;
         }
         init_trace("psa_create: main stream");
         if (hipDeviceGetAttribute(&c->cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->cus < 1) c->cus = 256;
-        PSA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-        PSA_HIP(hipStreamCreateWithFlags(&c->twin, hipStreamNonBlocking));
-        init_trace("psa_create: aux + twin streams");
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_pair), sizeof(double) * psa::kRow * psa::kRow));
-        init_trace("psa_create: first hipMalloc");
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_rank), psa::kRow * psa::kRow));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_sub), psa::kRow * psa::kRow));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_clsrank), psa::kRow * psa::kRow));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_delta), sizeof(double) * psa::kMaxRanks));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_symbol_planes), sizeof(unsigned) * 64));
-        PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_bad), sizeof(int)));
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_bad), sizeof(int), hipHostMallocDefault));
-        *c->h_bad = 0;
-        init_trace("psa_create: 7 more small hipMalloc + 1 hipHostMalloc");
-        PSA_TRY(ensure_tails(c, 1));
-        std::memset(c->h_tails, 0, sizeof(psa::SearchTail));
-        init_trace("psa_create: result tail (hipHostMalloc mapped)");
-        for (auto& s : c->slot) PSA_TRY(init_slot(s));
-        init_trace("psa_create: 2 slots (8 hipMalloc, 2 hipMemset, 4 events)");
+        // ---- the device arena: every fixed-size device buffer of the context, one allocation, one fill
+        {
+            size_t at = 0;
+            auto take = [&](size_t bytes) { const size_t o = at; at = (at + bytes + 255) & ~(size_t)255; return o; };
+            const size_t o_pair = take(sizeof(double) * psa::kRow * psa::kRow);
+            const size_t o_rank = take(psa::kRow * psa::kRow), o_sub = take(psa::kRow * psa::kRow), o_clsrank = take(psa::kRow * psa::kRow);
+            const size_t o_delta = take(sizeof(double) * psa::kMaxRanks);
+            const size_t o_arank = take(psa::kRow * psa::kRow), o_asub = take(psa::kRow * psa::kRow), o_aclsrank = take(psa::kRow * psa::kRow);
+            const size_t o_adelta = take(sizeof(double) * psa::kMaxRanks);
+            const size_t o_planes = take(sizeof(unsigned) * 64);
+            const size_t o_bad = take(sizeof(int));
+            const size_t o_ctl = take(128);
+            const size_t o_rawarr = take(64);
+            size_t o_scal[kSlots], o_cand[kSlots], o_upper[kSlots], o_rec[kSlots];
+            for (int k = 0; k < kSlots; ++k) {
+                o_scal[k] = take(sizeof(Scalars));
+                o_cand[k] = take(sizeof(int) * kCandCap);
+                o_upper[k] = take(sizeof(double) * kCandCap);
+                o_rec[k] = take(sizeof(psa::CandRec) * kCandCap);
+            }
+            PSA_HIP(hipMalloc(reinterpret_cast<void**>(&c->d_arena), at));
+            init_trace("psa_create: device arena (one hipMalloc)");
+            PSA_HIP(hipMemsetAsync(c->d_arena, 0, at, c->stream));       // flag, control words, counters, search scalars: zero
+            unsigned char* d = c->d_arena;
+            c->d_pair = reinterpret_cast<double*>(d + o_pair);
+            c->d_rank = d + o_rank;  c->d_sub = d + o_sub;  c->d_clsrank = d + o_clsrank;
+            c->d_delta = reinterpret_cast<double*>(d + o_delta);
+            c->d_alt_rank = d + o_arank;  c->d_alt_sub = d + o_asub;  c->d_alt_clsrank = d + o_aclsrank;
+            c->d_alt_delta = reinterpret_cast<double*>(d + o_adelta);
+            c->d_symbol_planes = reinterpret_cast<unsigned*>(d + o_planes);
+            c->d_bad = reinterpret_cast<int*>(d + o_bad);
+            c->d_ctl = reinterpret_cast<unsigned long long*>(d + o_ctl);
+            c->d_raw_arrivals = reinterpret_cast<unsigned*>(d + o_rawarr);
+            c->raw_arrived = 0u;
+            for (int k = 0; k < kSlots; ++k) {
+                SearchSlot& sl = c->slot[k];
+                sl.d_scal = reinterpret_cast<Scalars*>(d + o_scal[k]);
+                sl.d_cand = reinterpret_cast<int*>(d + o_cand[k]);
+                sl.d_cand_upper = reinterpret_cast<double*>(d + o_upper[k]);
+                sl.d_rec = reinterpret_cast<psa::CandRec*>(d + o_rec[k]);
+            }
+        }
+        // ---- the pinned arena (host-coherent, mapped): control words of the encode launches (two cache lines), the
+        // single search's result tail, the host copy of the alphabet flag
+        {
+            constexpr size_t kHostArena = 128 + 128 + 64;
+            static_assert(sizeof(psa::SearchTail) <= 128, "pinned arena");
+            PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&c->h_arena), kHostArena, hipHostMallocMapped | hipHostMallocCoherent));
+            std::memset(c->h_arena, 0, kHostArena);
+            unsigned char* hd = nullptr;
+            PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), c->h_arena, 0));
+            c->h_ctl = reinterpret_cast<unsigned long long*>(c->h_arena);
+            c->hd_ctl = reinterpret_cast<unsigned long long*>(hd);
+            c->h_tails = reinterpret_cast<psa::SearchTail*>(c->h_arena + 128);
+            c->hd_tails = reinterpret_cast<psa::SearchTail*>(hd + 128);
+            c->tails_cap = 1;
+            c->tails_in_arena = true;
+            for (auto& sl : c->slot) sl.d_tail = c->hd_tails;
+            c->h_bad = reinterpret_cast<int*>(c->h_arena + 256);
+            init_trace("psa_create: pinned arena (one hipHostMalloc)");
+        }
         {
             // class planes of every Seq1 symbol a over the Seq2 symbols b (group tables only):
             // word a: bit b = class(a, b) in {'*', '.'};  word 32+a: class in {':', '.'}
@@ -1691,12 +1741,9 @@ psa_status psa_create(int device, void* stream, psa_context** out)
                     if (sign == PSA_SIGN_COLON || sign == PSA_SIGN_DOT) planes[32 + a] |= 1u << b;
                 }
             PSA_HIP(hipMemcpyAsync(c->d_symbol_planes, planes, sizeof planes, hipMemcpyHostToDevice, c->stream));
+            PSA_HIP(hipStreamSynchronize(c->stream));       // (`planes` goes out of scope)
         }
-        PSA_HIP(hipMemsetAsync(c->d_bad, 0, sizeof(int), c->stream));
-        for (auto& ev : c->ev) PSA_HIP(hipEventCreate(&ev));
-        init_trace("psa_create: symbol planes copy + memset enqueued, 4 timing events");
-        PSA_HIP(hipStreamSynchronize(c->stream));
-        init_trace("psa_create: first stream synchronise");
+        init_trace("psa_create: arena fill + symbol planes copied, stream synchronised");
         return PSA_OK;
     }();
     if (st != PSA_OK) { psa_destroy(c); return st; }
@@ -1737,17 +1784,7 @@ void psa_destroy(psa_context* c)
     if (c->twin) (void)hipStreamSynchronize(c->twin);
     (void)hipFree(c->d_raw);
     (void)hipFree(c->d_s1);
-    (void)hipFree(c->d_pair);
-    (void)hipFree(c->d_rank);
-    (void)hipFree(c->d_sub);
-    (void)hipFree(c->d_clsrank);
-    (void)hipFree(c->d_delta);
-    (void)hipFree(c->d_symbol_planes);
-    (void)hipFree(c->d_alt_rank);
-    (void)hipFree(c->d_alt_sub);
-    (void)hipFree(c->d_alt_delta);
-    (void)hipFree(c->d_alt_clsrank);
-    (void)hipFree(c->d_bad);
+    (void)hipFree(c->d_arena);               // tables, flag, control words, the slots' scalars / lists / records
     for (auto& s : c->slot) free_slot(s);
     (void)hipFree(c->d_batch_rows);
     (void)hipFree(c->d_batch_cls);
@@ -1761,12 +1798,9 @@ void psa_destroy(psa_context* c)
         (void)hipFree(c->d_ring_arrivals[k]);
     }
     for (auto& ev : c->pool_events) (void)hipEventDestroy(ev);
-    if (c->h_tails) (void)hipHostFree(c->h_tails);
+    if (c->h_tails && !c->tails_in_arena) (void)hipHostFree(c->h_tails);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
-    if (c->h_ctl) (void)hipHostFree(c->h_ctl);
-    (void)hipFree(c->d_ctl);
-    (void)hipFree(c->d_raw_arrivals);
-    if (c->h_bad) (void)hipHostFree(c->h_bad);
+    if (c->h_arena) (void)hipHostFree(c->h_arena);
     for (auto& ev : c->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -2130,6 +2164,7 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
     PSA_TRY(check_ready(c, m, first, last));
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
+    PSA_TRY(ensure_batch_objects(c));
     const int nmodes = results1 ? 2 : 1;
     if (nmodes == 2) PSA_TRY(ensure_alt_tables(c));
     const TableSet tables[2] = {primary_tables(c), alternate_tables(c)};
@@ -2523,6 +2558,11 @@ psa_status psa_debug_rescore(psa_context* c, const int32_t* offsets, int count, 
 psa_status psa_set_profiling(psa_context* c, int on)
 {
     if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
+    if (on) {
+        DeviceScope device_scope;
+        PSA_TRY(ensure_device(c));
+        PSA_TRY(ensure_timing_events(c));
+    }
     c->profiling = on != 0;
     c->timing_valid = false;
     c->sum_search_ms = c->sum_kernel_ms = 0.0;

@@ -952,7 +952,7 @@ struct RescoreArgs {
     int fast_min_exp;               // smallest biased exponent of the running sum the walk handles
     int raw;                        // 1 (one-shot searches): s1 / s2 are the caller's raw ASCII (n1 / m bytes), not codes
     int n1;
-    int certify;                    // 1: try the certified segment sum first (certified_sum), the walk is its fallback
+    int certify;                    // 1: try the certified segment sum first (cert2_sum), the walk is its fallback
     double walk_slack;              // rigorous bound of |sequential fp64 prefix sum - order-free prefix sum| over the m chars
     // blockIdx.y = query of a batch launch: its state lies query_stride... further on (all 0 for one search)
     size_t s2_stride;               // bytes between the queries' codes
@@ -969,7 +969,7 @@ constexpr int kRescoreEpl = PSA_RESCORE_EPL;   // chars per lane and batch on th
 constexpr int kRescoreThreads = 512;
 constexpr int kRescoreChunk = 32768;    // chars whose class codes are staged in LDS at a time
 constexpr int kRescoreGrid = 64;        // workgroups; each takes candidates ci = block, block + 64, ...
-constexpr int kRescorePadLds = 36 * 1024;   // + ~35 KB static: a rescore and a count workgroup never share a CU
+constexpr int kRescorePadLds = 8 * 1024;    // + ~68 KB static: two rescore workgroups per CU, never one beside a count workgroup
 
 // Inclusive prefix sum of a 64-bit value over the 64 lanes, by DPP row shifts and row
 // broadcasts (register-to-register; no LDS round trips as __shfl_up would need).
@@ -1234,56 +1234,8 @@ __device__ __forceinline__ double walk_sum(double s, const unsigned char* s_code
 // binade, and the reference's addition fl(s_{k-1} + p_k) is the integer step S += R_e[class] (both multiples of
 // ulp_e, no tie — walk_sum's argument).  Every other char (a binade change, a prefix sum within slack of a power of
 // two, the first chars near zero) is a TRUE fp64 addition.
-//   parallel (whole workgroup): prefix class counts by a block scan, one fp64 add and a few compares per char, the
-//     true additions' positions written out in order (a second scan);
-//   parallel (one lane per true addition): the interior run in front of it is cnt[class] x R_e[class] from the prefix
-//     counts, e known from the certificate;
-//   serial (one wave, scalar): the first 64 chars as a plain chain, then per true addition "mantissa += run's
-//     integer, rebuild, one fp64 add" — a dozen events instead of 10,000 additions.
-// Nothing is assumed: a tie in a run's binade, a state that is not in the certified binade, a run that leaves it or
-// too many true additions send the candidate to walk_sum.
-constexpr int kCertMaxTrue = 64;          // true additions (behind the first 64 chars) one wave applies; more: the walk
-constexpr int kCertMaxFail = 256;         // 16-char segments looked at char by char
 constexpr int kCertChain = 64;            // chars summed as a plain chain first (the sum is still near zero there)
 constexpr int kCertSeg = 16;              // chars per segment: one thread settles a segment, or one 16-lane row its chars
-
-struct CertEvent {                        // one true addition
-    int pos;                              // its char
-    int pad;
-    unsigned long long before;            // class counts of the chars in front of it, 16 bits per class
-};
-struct CertSeg {                          // a segment that needs the per-char test
-    int seg;
-    int pad;
-    unsigned long long before;            // class counts of the chars in front of the segment
-};
-struct CertList {                         // per candidate, in LDS behind its class codes
-    unsigned long long at_head;           // class counts of the first kCertChain chars
-    unsigned long long total;             // class counts of all m chars
-    int nfail, nev;
-    CertSeg   fail[kCertMaxFail];
-    CertEvent ev[kCertMaxTrue];           // positions >= kCertChain (certify_chars: any order; certified_sum sorts them)
-};
-__host__ __device__ inline int cert_bytes() { return ((int)sizeof(CertList) + 15) & ~15; }
-
-template <int NT>
-__device__ __forceinline__ unsigned long long block_scan_exclusive(unsigned long long v, unsigned long long* s_wsum, int tid,
-                                                                   unsigned long long* total)
-{
-    const int lane = tid & 63, wave = tid >> 6;
-    const unsigned long long incl = (unsigned long long)wave_scan_inclusive((long long)v);
-    if (lane == 63) s_wsum[wave] = incl;                // (s_wsum is free: every caller ends behind a barrier)
-    __syncthreads();
-    unsigned long long base = incl - v, all = 0ull;
-#pragma unroll
-    for (int w = 0; w < NT / 64; ++w) {
-        const unsigned long long x = s_wsum[w];
-        if (w < wave) base += x;
-        all += x;
-    }
-    if (total) *total = all;
-    return base;
-}
 
 // scans inside the 16-lane rows of a wave (DPP row shifts; lanes without a source add nothing)
 template <int CTRL>
@@ -1302,15 +1254,6 @@ __device__ __forceinline__ double row_scan_inclusive_f64(double v)
     v = row_add_f64<0x118>(v);
     return v;
 }
-__device__ __forceinline__ long long row_scan_inclusive_i64(long long v)
-{
-    v = dpp_add<0x111, 0xf>(v);
-    v = dpp_add<0x112, 0xf>(v);
-    v = dpp_add<0x114, 0xf>(v);
-    v = dpp_add<0x118, 0xf>(v);
-    return v;
-}
-
 // |x| at least `margin` inside its binade (2^e, 2^(e+1)), e in the integer walk's range?  With lo = 2^e:
 // min(|x| - lo, lo - (|x| - lo)) >= margin (both differences are exact).  hi32 = sign, exponent and upper mantissa.
 __device__ __forceinline__ bool cert_inside(double x, double margin, double amin, double amax, unsigned& hi32)
@@ -1332,221 +1275,380 @@ __device__ __forceinline__ double cert_value(unsigned long long counts, const do
     return p;
 }
 
-// Parallel part (every thread of the workgroup; contains workgroup barriers).  Level 1, a thread per 16-char segment:
-// every prefix sum of a segment lies within A = sum |p_i| of the sum in front of it, so if that sum is A + slack inside
-// its binade every char of the segment is interior — most segments.  Level 2, a 16-lane row per remaining segment, a
-// lane per char: the prefix sums by a row scan, the test per char, a true addition -> list->ev (any order) with the
-// class counts in front of it (cert_true_additions: how many).
-template <int NT>
-__device__ __forceinline__ void certify_chars(const unsigned char* s_codes, int m, const double* s_class, double slack,
-                                              int fast_min_exp, CertList* list, unsigned long long* s_wsum, int tid)
+// =====================================================================================================================
+// The certificate and the certified sum (round 4 form; round 3's kept an unordered list of at most 64 true additions,
+// which one wave sorted, and rebuilt the sum's mantissa per event):
+//   * inputs whose running sum hovers near zero or near a power of two (low-entropy alphabets: ACGT with the README
+//     weights has 154 true additions behind the first 64 chars) used to exceed the list and were WALKED (64-130 us);
+//     now up to kCert2MaxEv true additions are applied, 64 at a time;
+//   * a shorter critical path in the search's tail: classification and the certificate's first level are ONE pass over
+//     a thread's 16 chars, the head chain runs on a spare wave beside level 2, an event is two v_add_f64.
+// Data of one candidate (LDS, behind its class codes; CertLayout):
+//   seg_before[seg]  class counts (16 bits per class) of the chars in front of 16-char segment `seg`
+//   bitmap           bit k set = char k is a TRUE fp64 addition (k >= kCertChain); level 2 sets the bits, so the true
+//                    additions come out in ascending order by themselves (the first form sorted an unordered list)
+//   fail[]           segments level 1 could not settle (any order)
+//   ev[]             positions of the true additions, ascending (compacted from the bitmap by the summing wave)
+// and per search the table rt[e - emin][class] = round(p_class / ulp_e) with a "tie" bit per binade, filled by spare
+// threads while the others classify (the first form recomputed it per event with 64-bit shifts).
+// An EVENT = the interior run in front of a true addition + that addition.  The run's sum is an integer number of
+// ulp_e, D = sum_c cnt_c * rt[e][c] (exact, wrapping 64-bit; the certified total fits 53 bits); state and D are both
+// multiples of ulp_e and the certificate says state + D stays inside binade e, so ONE v_add_f64 adds the run EXACTLY
+// (no rounding can occur), a second one is the reference's own addition of the true char: two dependent adds and a
+// check of the exponents per event instead of the first form's mantissa rebuild (87 -> ~30 ns per event).
+// Nothing is assumed: a state or a state + D whose sign/exponent is not the certified one, a binade with a tie or
+// outside the table, more than kCert2MaxEv true additions or kCert2MaxFail unsettled segments send the candidate to
+// walk_sum.  Tested bit for bit against the oracle for every offset (test_rescore_walk_is_bit_exact, the soak).
+constexpr int kCert2MaxFail = 1024;       // unsettled 16-char segments per candidate
+constexpr int kCert2MaxEv = 1024;         // true additions per candidate the summing wave applies (64 at a time)
+constexpr int kCert2Rows = 48;            // binades of the rounded-class-value table
+
+struct Cert2Table {                       // per search
+    long long rt[kCert2Rows][4];
+    unsigned long long tie;               // bit row: an addend ties in that binade (round-half-even: the walk's business)
+    int emin, pad;
+};
+struct Cert2Head {                        // per candidate
+    unsigned long long total;             // class counts of all m chars
+    double head_sum;                      // the reference's sum over the first kCertChain chars
+    int nfail;
+    int pad;
+};
+constexpr int kCert2Summary = 64;           // words of the bitmap's summary (bit w: bitmap word w is not zero): 65,536 chars
+struct Cert2Layout { int seg_before, segbits, bitmap, summary, fail, ev, bytes, nseg, nwords; };
+__host__ __device__ inline Cert2Layout cert2_layout(int m)
 {
-    const int lane = tid & 63, wave = tid >> 6;
+    Cert2Layout L;
+    L.nseg = (m + kCertSeg - 1) / kCertSeg;
+    L.nwords = (m + 31) / 32;
+    int at = (int)sizeof(Cert2Head);
+    L.seg_before = at;  at += 8 * (L.nseg + 1);
+    L.segbits = at;     at += 4 * ((L.nseg + 1) & ~1);       // per segment: bit t = low class bit of char t, bit 16 + t = high
+    L.bitmap = at;      at += 4 * ((L.nwords + 1) & ~1);
+    L.summary = at;     at += 4 * kCert2Summary;
+    L.fail = at;        at += 2 * kCert2MaxFail;             // (pass 4 reuses it for the list of non-zero bitmap words)
+    L.ev = at;          at += 2 * kCert2MaxEv;
+    L.bytes = (at + 15) & ~15;
+    return L;
+}
+static_assert(sizeof(Cert2Head) == 24, "cert2_layout");
+
+// the table (any kCert2Rows * 4 threads; `idx` = this thread's entry).  tie bits are or-ed in: zero `tie` first.
+__device__ __forceinline__ void cert2_fill_table(Cert2Table* tb, const double* s_class, int fast_min_exp, int idx)
+{
+    const int row = idx >> 2, c = idx & 3;
+    const int e = fast_min_exp + row;
+    const unsigned long long pb = (unsigned long long)__double_as_longlong(s_class[c]);
+    const int ep = (int)((pb >> 52) & 0x7ff);
+    long long r = 0;
+    bool tie = false;
+    if (ep != 0) {                                           // zero stays 0 (subnormal weights: no certificate at all)
+        const unsigned long long mp = (pb & 0xfffffffffffffull) | (1ull << 52);
+        const int d = e - ep;                                // >= 2: fast_min_exp is two binades above the largest addend
+        if (d < 2 || e >= 0x7fe) tie = true;                 // (never a certified binade)
+        else if (d <= 53) {
+            const unsigned long long half = 1ull << (d - 1);
+            tie = (mp & ((half << 1) - 1)) == half;
+            const long long mag = (long long)((mp + half) >> d);
+            r = (pb >> 63) ? -mag : mag;
+        }
+    }
+    tb->rt[row][c] = r;
+    if (tie) atomicOr(&tb->tie, 1ull << row);
+    if (idx == 0) tb->emin = fast_min_exp;
+}
+
+// ---- pass 1 (every thread): the thread's 16-char segments of one candidate -------------------------------------------
+// classifies them (class | rank codes into LDS, `key` = max(rank << 32 | ~i) as classify_chars), counts their classes
+// (returned: all of the thread's segments together, 16 bits per class) and leaves the per-segment counts where pass 2
+// finds them (seg_before[seg] = the counts of the thread's segments in front of `seg`).  Segments behind m are padding
+// (class 4: the walk's over-read and level 2's rows read up to 528 chars behind m).
+// class counts (16 bits per class) of the first `r` chars of a segment from its class bits
+__device__ __forceinline__ unsigned long long cert2_counts_of_bits(unsigned bits, int r)
+{
+    const unsigned pm = (1u << r) - 1u;                      // r <= 16
+    const unsigned b0 = bits & pm, b1 = (bits >> 16) & pm;
+    const unsigned n1 = __popc(b0 & ~b1), n2 = __popc(b1 & ~b0), n3 = __popc(b0 & b1);
+    const unsigned n0 = (unsigned)r - n1 - n2 - n3;
+    return (unsigned long long)(n0 | (n1 << 16)) | ((unsigned long long)(n2 | (n3 << 16)) << 32);
+}
+
+template <int NT, bool RAW>
+__device__ __forceinline__ unsigned long long cert2_classify(const unsigned char* __restrict__ s1, const unsigned char* __restrict__ s2,
+                                                             const unsigned char* s_clsrank, unsigned char* s_codes, int m,
+                                                             unsigned long long* seg_before, unsigned* segbits, int tid,
+                                                             unsigned long long& key, int limit1, int limit2)
+{
     const int nseg = (m + kCertSeg - 1) / kCertSeg;
-    const int per = (nseg + NT - 1) / NT;               // segments per thread (1 up to 16,384 chars with 1,024 threads)
-    const int seg0 = tid * per;
+    const int nseg_pad = (m + 64 * kRescoreEpl + 16 + kCertSeg - 1) / kCertSeg;      // codes are written up to here
+    const int per = (nseg + NT - 1) / NT;                    // 1 up to 16,384 chars with 1,024 threads
+    const int per_pad = per + (nseg_pad - nseg + NT - 1) / NT;
+    unsigned long long mine = 0ull;
+    for (int q = 0; q < per_pad; ++q) {
+        const int seg = q < per ? tid * per + q : nseg + (q - per) * NT + tid;      // real segments first, then the padding's
+        const int k0 = seg * kCertSeg;
+        if (q < per && seg < nseg) {
+            unsigned w1[4], w2[4];
+#ifdef PSA_PHASE_TIMING
+            if (tid == 0) g_phase_ts[1005][0] = wall_clock64();
+#endif
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                w2[x] = load_codes4<RAW>(s2, k0 + 4 * x, limit2);      // encoded buffers are padded with kCodePad (class 4,
+                w1[x] = load_codes4<RAW>(s1, k0 + 4 * x, limit1);      // rank 0) far beyond their ends, raw ones read as such
+            }
+#ifdef PSA_PHASE_TIMING
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(w1[0]), "+v"(w1[1]), "+v"(w1[2]), "+v"(w1[3]), "+v"(w2[0]), "+v"(w2[1]), "+v"(w2[2]), "+v"(w2[3]));
+            if (tid == 0) g_phase_ts[1005][1] = wall_clock64();
+#endif
+            // per char: one table byte (class | rank << 3; chars behind m come out as class 4, rank 0 by themselves), its
+            // place in the packed codes, the running best (rank, lowest char) and the two class bits — 32-bit ops only
+            unsigned packed[4], b0 = 0u, b1 = 0u, best = 0u;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                packed[x] = 0u;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int t = 4 * x + j;
+                    const unsigned cr = s_clsrank[((w2[x] >> (8 * j)) & 0xffu) * kRow + ((w1[x] >> (8 * j)) & 0xffu)];
+                    packed[x] |= cr << (8 * j);
+                    const unsigned cand = ((cr >> 3) << 4) | (unsigned)(15 - t);
+                    best = cand > best ? cand : best;
+                    b0 |= (cr & 1u) << t;
+                    b1 |= ((cr >> 1) & 1u) << t;
+                }
+            }
+            *reinterpret_cast<uint4*>(s_codes + k0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+#ifdef PSA_PHASE_TIMING
+            if (tid == 0) g_phase_ts[1005][2] = wall_clock64();
+#endif
+            // (cpu_funcs.c:287-294: strictly better delta only, so the first char of the best rank stands)
+            const unsigned long long k2 = ((unsigned long long)(best >> 4) << 32) | (0xffffffffu - (unsigned)(k0 + 15 - (int)(best & 15u)));
+            key = k2 > key ? k2 : key;
+            if (seg_before) {
+                const int valid = m - k0 < kCertSeg ? m - k0 : kCertSeg;
+                const unsigned bits = b0 | (b1 << 16);
+                segbits[seg] = bits;
+                seg_before[seg] = mine;                      // (made absolute by cert2_level1, behind the scan's barrier)
+                mine += cert2_counts_of_bits(bits, valid);
+            }
+        } else if (q >= per && seg < nseg_pad) {
+            *reinterpret_cast<uint4*>(s_codes + k0) = make_uint4(0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u);
+        }
+    }
+    return mine;
+}
+
+// ---- pass 2 (every thread, behind the barrier that follows the block scan's wave totals) ----------------------------
+// `before` = class counts in front of the thread's first segment (block scan of cert2_classify's return values).
+// Level 1: all prefix sums of a segment lie within A = sum |p_i| of the sum in front of it; that sum A + slack inside its
+// binade settles the segment.  The others go to fail[].  head->nfail must be zero (and the bitmap clear) by now.
+template <int NT>
+__device__ __forceinline__ void cert2_level1(const unsigned char* s_codes, int m, const double* s_class, double slack,
+                                             int fast_min_exp, unsigned char* cert, unsigned long long before, int tid)
+{
+    const Cert2Layout L = cert2_layout(m);
+    Cert2Head* head = reinterpret_cast<Cert2Head*>(cert);
+    unsigned long long* seg_before = reinterpret_cast<unsigned long long*>(cert + L.seg_before);
+    const unsigned* segbits = reinterpret_cast<const unsigned*>(cert + L.segbits);
+    unsigned short* fail = reinterpret_cast<unsigned short*>(cert + L.fail);
+    (void)s_codes;
+    const int per = (L.nseg + NT - 1) / NT;
     const double amin = __longlong_as_double((long long)((unsigned long long)(fast_min_exp < 1 ? 1 : fast_min_exp) << 52));
     const double amax = __longlong_as_double(0x7fd0000000000000ll);
-    if (tid == 0) { list->nfail = 0; list->nev = 0; }
-    // class counts and reach of this thread's segments
-    auto segment = [&](int seg, unsigned long long& counts) {
-        counts = 0ull;
+    for (int q = 0; q < per; ++q) {
+        const int seg = tid * per + q;
+        if (seg >= L.nseg) break;
         const int k0 = seg * kCertSeg;
-        if (k0 >= m) return;
-        const uint4 w4 = *reinterpret_cast<const uint4*>(s_codes + k0);     // (the codes behind m are class 4: counted nowhere)
-        const unsigned w[4] = {w4.x, w4.y, w4.z, w4.w};
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned cls = (w[q] >> (8 * j)) & 7u;
-                if (cls < 4u) counts += 1ull << (16 * cls);
-            }
-    };
-    unsigned long long local = 0ull;
-    for (int s = 0; s < per; ++s) {
-        unsigned long long c;
-        segment(seg0 + s, c);
-        local += c;
-    }
-    unsigned long long all = 0ull;
-    unsigned long long before = block_scan_exclusive<NT>(local, s_wsum, tid, &all);     // (its barrier orders nfail = 0)
-    if (tid == 0) list->total = all;
-    for (int s = 0; s < per; ++s) {
-        const int seg = seg0 + s;
-        unsigned long long c = local;
-        if (per > 1) segment(seg, c);
-        const int k0 = seg * kCertSeg;
-        if (k0 == kCertChain) list->at_head = before;
-        if (k0 < m && k0 + kCertSeg > kCertChain) {
+        const unsigned long long b = before + seg_before[seg];            // (relative to the thread's first segment so far)
+        seg_before[seg] = b;
+        if (k0 + kCertSeg > kCertChain) {
+            // the segment's own counts: from its class bits
+            const unsigned long long n = cert2_counts_of_bits(segbits[seg], m - k0 < kCertSeg ? m - k0 : kCertSeg);
             double reach = 0.0;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) reach += fabs(s_class[q]) * (double)(unsigned)((c >> (16 * q)) & 0xffffull);
+            for (int cc = 0; cc < 4; ++cc) reach += fabs(s_class[cc]) * (double)(unsigned)((n >> (16 * cc)) & 0xffffull);
             unsigned hi32;
-            if (!cert_inside(cert_value(before, s_class), reach * 1.0000001 + slack, amin, amax, hi32)) {
-                const int slot = atomicAdd(&list->nfail, 1);
-                if (slot < kCertMaxFail) {
-                    list->fail[slot].seg = seg;
-                    list->fail[slot].before = before;
-                }
-            }
-        }
-        before += c;
-    }
-    __syncthreads();
-    const int nfail = list->nfail;
-    if (nfail <= kCertMaxFail) {
-        const int row = lane >> 4, col = lane & 15;
-        for (int f0 = wave * 4; f0 < nfail; f0 += (NT / 64) * 4) {
-            const int f = f0 + row;
-            const bool live = f < nfail;
-            const int k = (live ? list->fail[f].seg : 0) * kCertSeg + col;
-            const unsigned long long cb = live ? list->fail[f].before : 0ull;
-            const unsigned cls = s_codes[k] & 7u;
-            const double v = s_class[cls];                                           // (+0.0 behind m)
-            const double p_front = cert_value(cb, s_class);
-            const double p = p_front + row_scan_inclusive_f64(v);                    // after this lane's char
-            // the sum in front of this lane's char: the left neighbour's, the segment's own for the first lane
-            const long long pb = __double_as_longlong(p);
-            const int nlo = __builtin_amdgcn_update_dpp(0, (int)pb, 0x111, 0xf, 0xf, false);
-            const int nhi = __builtin_amdgcn_update_dpp(0, (int)(pb >> 32), 0x111, 0xf, 0xf, false);
-            const double p_prev = col == 0 ? p_front
-                                           : __longlong_as_double((long long)(((unsigned long long)(unsigned)nhi << 32) | (unsigned)nlo));
-            unsigned hi, hi_prev;
-            const bool safe = cert_inside(p, slack, amin, amax, hi);
-            const bool safe_prev = cert_inside(p_prev, slack, amin, amax, hi_prev);
-            const bool interior = safe && safe_prev && ((hi ^ hi_prev) >> 20) == 0u;   // same sign and exponent
-            const unsigned long long inc = cls < 4u ? 1ull << (16 * cls) : 0ull;
-            const unsigned long long cnt_before = cb + (unsigned long long)row_scan_inclusive_i64((long long)inc) - inc;
-            if (live && !interior && k >= kCertChain && k < m) {
-                const int slot = atomicAdd(&list->nev, 1);
-                if (slot < kCertMaxTrue) {
-                    list->ev[slot].pos = k;
-                    list->ev[slot].before = cnt_before;
-                }
+            if (!cert_inside(cert_value(b, s_class), reach * 1.0000001 + slack, amin, amax, hi32)) {
+                const int slot = atomicAdd(&head->nfail, 1);
+                if (slot < kCert2MaxFail) fail[slot] = (unsigned short)seg;
             }
         }
     }
-    __syncthreads();
 }
 
-// how many true additions certify_chars found (more than kCertMaxTrue: a list overflowed, walk instead)
-__device__ __forceinline__ int cert_true_additions(const CertList* list)
+// ---- pass 3 (every thread, behind a barrier): level 2, a 16-lane row per unsettled segment, a lane per char ----------
+template <int NT>
+__device__ __forceinline__ void cert2_level2(const unsigned char* s_codes, int m, const double* s_class, double slack,
+                                             int fast_min_exp, unsigned char* cert, int tid)
 {
-    return list->nfail <= kCertMaxFail ? list->nev : kCertMaxTrue + 1;
+    const Cert2Layout L = cert2_layout(m);
+    const Cert2Head* head = reinterpret_cast<const Cert2Head*>(cert);
+    const unsigned long long* seg_before = reinterpret_cast<const unsigned long long*>(cert + L.seg_before);
+    const unsigned short* fail = reinterpret_cast<const unsigned short*>(cert + L.fail);
+    unsigned* bitmap = reinterpret_cast<unsigned*>(cert + L.bitmap);
+    unsigned* summary = reinterpret_cast<unsigned*>(cert + L.summary);
+    const int lane = tid & 63, wave = tid >> 6;
+    const int nfail = head->nfail;
+    if (nfail > kCert2MaxFail) return;
+    const double amin = __longlong_as_double((long long)((unsigned long long)(fast_min_exp < 1 ? 1 : fast_min_exp) << 52));
+    const double amax = __longlong_as_double(0x7fd0000000000000ll);
+    const int row = lane >> 4, col = lane & 15;
+    for (int f0 = wave * 4; f0 < nfail; f0 += (NT / 64) * 4) {
+        const int f = f0 + row;
+        const bool live = f < nfail;
+        const int seg = live ? (int)fail[f] : 0;
+        const int k = seg * kCertSeg + col;
+        const unsigned long long cb = live ? seg_before[seg] : 0ull;
+        const unsigned cls = s_codes[k] & 7u;
+        const double v = s_class[cls];                                           // (+0.0 behind m)
+        const double p_front = cert_value(cb, s_class);
+        const double p = p_front + row_scan_inclusive_f64(v);                    // after this lane's char
+        // the sum in front of this lane's char: the left neighbour's, the segment's own for the first lane
+        const long long pb = __double_as_longlong(p);
+        const int nlo = __builtin_amdgcn_update_dpp(0, (int)pb, 0x111, 0xf, 0xf, false);
+        const int nhi = __builtin_amdgcn_update_dpp(0, (int)(pb >> 32), 0x111, 0xf, 0xf, false);
+        const double p_prev = col == 0 ? p_front
+                                       : __longlong_as_double((long long)(((unsigned long long)(unsigned)nhi << 32) | (unsigned)nlo));
+        unsigned hi, hi_prev;
+        const bool safe = cert_inside(p, slack, amin, amax, hi);
+        const bool safe_prev = cert_inside(p_prev, slack, amin, amax, hi_prev);
+        const bool interior = safe && safe_prev && ((hi ^ hi_prev) >> 20) == 0u;   // same sign and exponent
+        const bool is_true = live && !interior && k >= kCertChain && k < m;
+        const unsigned long long mask = __ballot(is_true);
+        const unsigned bits = (unsigned)(mask >> (16 * row)) & 0xffffu;
+        if (col == 0 && bits) {
+            atomicOr(&bitmap[seg >> 1], bits << (16 * (seg & 1)));
+            atomicOr(&summary[seg >> 6], 1u << ((seg >> 1) & 31));
+        }
+    }
 }
 
-// Serial part: ONE wave (all 64 lanes, same arguments).  Returns false when the candidate has to be walked instead.
-__device__ __forceinline__ bool certified_sum(const unsigned char* s_codes, int m, const double* s_class,
-                                              CertList* list, int ntrue, WalkScratch* ws, int lane, double& s_out)
+// class counts of chars [0, x), 0 <= x <= m: the segment's prefix + the chars of its segment in front of x
+__device__ __forceinline__ unsigned long long cert2_counts_before(const unsigned* segbits, const unsigned long long* seg_before,
+                                                                  int x, int m, unsigned long long total)
 {
-    if (ntrue > kCertMaxTrue) return false;
-    static_assert(kCertMaxTrue == 64, "one lane per true addition");
+    if (x >= m) return total;
+    const int seg = x >> 4;
+    return seg_before[seg] + cert2_counts_of_bits(segbits[seg], x & 15);
+}
+
+// ---- the sum: ONE wave (all 64 lanes, same arguments), behind the barrier that follows level 2 ------------------------
+// Returns false when the candidate has to be walked instead.
+__device__ __forceinline__ bool cert2_sum(const unsigned char* s_codes, int m, const double* s_class, unsigned char* cert,
+                                          const Cert2Table* tb, int lane, double& s_out)
+{
 #ifdef PSA_PHASE_TIMING
 #define PSA_SPHASE(k) do { if (lane == 0) g_phase_ts[1004][k] = wall_clock64(); } while (0)
 #else
 #define PSA_SPHASE(k) do { } while (0)
 #endif
+    const Cert2Layout L = cert2_layout(m);
+    const Cert2Head* head = reinterpret_cast<const Cert2Head*>(cert);
+    const unsigned long long* seg_before = reinterpret_cast<const unsigned long long*>(cert + L.seg_before);
+    const unsigned* segbits = reinterpret_cast<const unsigned*>(cert + L.segbits);
+    const unsigned* bitmap = reinterpret_cast<const unsigned*>(cert + L.bitmap);
+    const unsigned* summary = reinterpret_cast<const unsigned*>(cert + L.summary);
+    unsigned short* nzw = reinterpret_cast<unsigned short*>(cert + L.fail);     // (the fail list is dead behind level 2)
+    unsigned short* ev = reinterpret_cast<unsigned short*>(cert + L.ev);
+    if (head->nfail > kCert2MaxFail) return false;
     PSA_SPHASE(0);
-    // ---- the true additions in ascending order: every lane ranks its own entry, then all store back
+    // ---- the true additions in ascending order, compacted from the bitmap in two steps: the summary (a lane per 32
+    // bitmap words) gives the non-zero words in order, then a lane per non-zero word gives the positions
+    int nzw_count;
     {
-        const int pos = lane < ntrue ? list->ev[lane].pos : 0x7fffffff;
-        const unsigned long long before = lane < ntrue ? list->ev[lane].before : 0ull;
-        int rank = 0;
-        for (int j = 0; j < ntrue; ++j) rank += __builtin_amdgcn_readlane(pos, j) < pos ? 1 : 0;
-        __builtin_amdgcn_wave_barrier();
-        if (lane < ntrue) {
-            list->ev[rank].pos = pos;
-            list->ev[rank].before = before;
+        const unsigned sw = lane < (L.nwords + 31) / 32 ? summary[lane] : 0u;
+        const int mine = __popc(sw);
+        const int incl = (int)wave_scan_inclusive((long long)mine);
+        nzw_count = __builtin_amdgcn_readlane(incl, 63);
+        if (nzw_count > kCert2MaxFail) return false;
+        int at = incl - mine;
+        unsigned w = sw;
+        while (w) {
+            nzw[at++] = (unsigned short)(32 * lane + __ffs((int)w) - 1);
+            w &= w - 1u;
         }
-        __builtin_amdgcn_wave_barrier();
     }
+    __builtin_amdgcn_wave_barrier();
+    int nev = 0;
+    for (int c0 = 0; c0 < nzw_count; c0 += 64) {
+        const int wi = c0 + lane < nzw_count ? (int)nzw[c0 + lane] : -1;
+        unsigned w = wi >= 0 ? bitmap[wi] : 0u;
+        const int mine = __popc(w);
+        const int incl = (int)wave_scan_inclusive((long long)mine);
+        int at = nev + incl - mine;
+        nev += __builtin_amdgcn_readlane(incl, 63);
+        if (nev > kCert2MaxEv) return false;
+        while (w) {
+            ev[at++] = (unsigned short)(32 * wi + __ffs((int)w) - 1);
+            w &= w - 1u;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
     PSA_SPHASE(1);
-    // ---- the first chars: plain chain (cpu_funcs.c:278), lanes past the end hold +0.0
-    const int head = m < kCertChain ? m : kCertChain;
-    double s = chain64(0.0, lane < head ? s_class[s_codes[lane] & 7u] : 0.0);
-    (void)ws;
+    const int head_n = m < kCertChain ? m : kCertChain;
+    const unsigned long long total = head->total;
+    const unsigned long long at_head = cert2_counts_before(segbits, seg_before, head_n, m, total);
+    double s = head->head_sum;                            // the first chars: a plain chain, summed beside level 2
     PSA_SPHASE(2);
-    // ---- events: event i = the interior run behind the previous true addition (or the head) + true addition i;
-    // the last event (i == ntrue) is the run up to m alone.  One lane per event prepares it, then the wave applies
-    // the events in order.
-    bool failed = false;
-    for (int i0 = 0; i0 <= ntrue && !failed; i0 += 64) {
+    // ---- events, 64 at a time: a lane prepares event i = the interior run behind true addition i - 1 (or the head) and
+    // true addition i; the last event (i == nev) is the run up to m alone.  Then the wave applies them in order.
+    unsigned chk = 0u;
+    for (int i0 = 0; i0 <= nev; i0 += 64) {
         const int i = i0 + lane;
-        const bool live = i <= ntrue;
-        unsigned long long delta = 0ull;
-        unsigned key = 0u;
+        double dv = 0.0, v = 0.0;
+        unsigned keyhi = 0u, kmask = 0u;
         bool bad = false;
-        double v = 0.0;
-        if (live) {
-            int at = m, from = head;
-            unsigned long long cb = list->total, ca = list->at_head;      // class counts in front of `at` / `from`
-            if (i < ntrue) {
-                at = list->ev[i].pos;
-                cb = list->ev[i].before;
+        if (i <= nev) {
+            int at = m, from = head_n;
+            unsigned long long ca = at_head;
+            if (i < nev) {
+                at = (int)ev[i];
                 v = s_class[s_codes[at] & 7u];
             }
             if (i > 0) {
-                const int prev = list->ev[i - 1].pos;
-                const unsigned cls = s_codes[prev] & 7u;
-                from = prev + 1;
-                ca = list->ev[i - 1].before + (cls < 4u ? 1ull << (16 * cls) : 0ull);
+                from = (int)ev[i - 1] + 1;
+                ca = cert2_counts_before(segbits, seg_before, from, m, total);
             }
             if (at > from) {
+                const unsigned long long cb = cert2_counts_before(segbits, seg_before, at, m, total);
                 const unsigned long long cnt = cb - ca;                    // per class, no borrows: counts only grow
                 // the run's binade: the certified one of the sum in front of it
-                key = (unsigned)((unsigned long long)__double_as_longlong(cert_value(ca, s_class)) >> 52);
+                const unsigned key = (unsigned)((unsigned long long)__double_as_longlong(cert_value(ca, s_class)) >> 52);
                 const int e = (int)(key & 0x7ffu);
+                const int row = e - tb->emin;
+                if (row < 0 || row >= kCert2Rows || ((tb->tie >> (row & 63)) & 1ull)) bad = true;
+                else {
+                    unsigned long long delta = 0ull;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const unsigned long long pb = (unsigned long long)__double_as_longlong(s_class[c]);
-                    const int ep = (int)((pb >> 52) & 0x7ff);
-                    long long r = 0;
-                    if (ep != 0) {
-                        const unsigned long long mp = (pb & 0xfffffffffffffull) | (1ull << 52);
-                        const int d = e - ep;
-                        if (d < 2) bad = true;                              // (not a certified binade: fast_min_exp)
-                        else if (d <= 53) {
-                            const unsigned long long half = 1ull << (d - 1);
-                            bad |= (mp & ((half << 1) - 1)) == half;        // a tie: the walk's business
-                            const long long mag = (long long)((mp + half) >> d);
-                            r = (pb >> 63) ? -mag : mag;
-                        }
-                    }
-                    delta += ((cnt >> (16 * c)) & 0xffffull) * (unsigned long long)r;   // (wraps; the certified total fits)
+                    for (int c = 0; c < 4; ++c)
+                        delta += ((cnt >> (16 * c)) & 0xffffull) * (unsigned long long)tb->rt[row][c];   // (wraps; the certified total fits)
+                    dv = ldexp((double)(long long)delta, e - 1075);        // D = delta ulp_e, exact: |delta| < 2^53
                 }
-                key |= 0x1000u;                                             // "has a run"
+                keyhi = key << 20;
+                kmask = 0xfff00000u;
             }
         }
         if (__ballot(bad) != 0ull) return false;
         PSA_SPHASE(3);
-        // Applied in order, straight-line: mantissa + the run's integer (0 without a run: the rebuild is the identity;
-        // its sign is the certified binade's, which the state's bits are checked against), the checks folded into one
-        // flag, then the reference's own addition (+0.0 behind the last true addition).  Two events per trip: the
-        // lane reads of the second do not wait for the first one's arithmetic.
-        const int count = ntrue + 1 - i0 < 64 ? ntrue + 1 - i0 : 64;
-        const long long sdelta = (key & 0x800u) ? -(long long)delta : (long long)delta;
-        // The state lives in two VECTOR registers the compiler cannot prove uniform (the empty asm): every step of an
-        // event is then a VALU instruction fed by the event's scalars (v_readlane) — and-or, 64-bit add, and-or,
-        // v_add_f64, ~40 cycles of dependent issue.  Left to itself the compiler keeps the (uniform) state in scalar
-        // registers and crosses between the scalar and the vector unit four times per event (270 cycles each).
+        const int count = nev + 1 - i0 < 64 ? nev + 1 - i0 : 64;
+        // The state lives in a VECTOR register pair the compiler cannot prove uniform (the empty asm): an event is then
+        // v_add_f64 (the run, exact), two xor / one and-or for the check, v_add_f64 (the true addition), fed by the event's
+        // scalars (v_readlane).  Left to itself the compiler keeps the uniform state in scalar registers and crosses
+        // between the scalar and the vector unit for every step.
         unsigned s_lo = (unsigned)(unsigned long long)__double_as_longlong(s);
         unsigned s_hi = (unsigned)((unsigned long long)__double_as_longlong(s) >> 32);
-        unsigned bad_acc = 0u;
         asm volatile("" : "+v"(s_lo), "+v"(s_hi));
         auto apply = [&](int j) {
-            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)key, j);
-            const unsigned long long dj = (unsigned long long)readlane64(sdelta, j);
+            const unsigned kj = (unsigned)__builtin_amdgcn_readlane((int)keyhi, j);
+            const unsigned mj = (unsigned)__builtin_amdgcn_readlane((int)kmask, j);
+            const double dj = __longlong_as_double(readlane64(__double_as_longlong(dv), j));
             const double vj = __longlong_as_double(readlane64(__double_as_longlong(v), j));
-            // |sum| in ulps of its binade, plus the run's integer
-            const unsigned long long S = ((((unsigned long long)((s_hi & 0xfffffu) | 0x100000u)) << 32) | s_lo) + dj;
-            // the state is in the certified binade and the run stays strictly inside it (the certificate says both):
-            // 2^52 < S < 2^53  <=>  S - 2^52 - 1 < 2^52 - 1 (unsigned)
-            const bool stays = (S - ((1ull << 52) + 1ull)) < ((1ull << 52) - 1ull);
-            const bool fine = ((kj & 0x1000u) == 0u) | (((s_hi >> 20) == (kj & 0xfffu)) & stays);
-            bad_acc |= fine ? 0u : 1u;
-            const unsigned n_hi = (s_hi & 0xfff00000u) | ((unsigned)(S >> 32) & 0xfffffu);
-            const double x = __longlong_as_double((long long)(((unsigned long long)n_hi << 32) | (unsigned)S)) + vj;
+            const double s0 = __longlong_as_double((long long)(((unsigned long long)s_hi << 32) | s_lo));
+            const double s1 = s0 + dj;                     // the interior run: exact (both multiples of ulp_e, inside binade e)
+            const unsigned h1 = (unsigned)((unsigned long long)__double_as_longlong(s1) >> 32);
+            chk |= ((s_hi ^ kj) | (h1 ^ kj)) & mj;         // state and state + run carry the certified sign and exponent
+            const double x = s1 + vj;                      // the reference's own addition (+0.0 behind the last one)
             s_lo = (unsigned)(unsigned long long)__double_as_longlong(x);
             s_hi = (unsigned)((unsigned long long)__double_as_longlong(x) >> 32);
         };
@@ -1557,16 +1659,16 @@ __device__ __forceinline__ bool certified_sum(const unsigned char* s_codes, int 
         }
         if (j < count) apply(j);
         s = __longlong_as_double((long long)(((unsigned long long)s_hi << 32) | s_lo));
-        failed = __ballot(bad_acc != 0u) != 0ull;
+        if (__ballot(chk != 0u) != 0ull) return false;
     }
     PSA_SPHASE(4);
-    if (failed) return false;
     s_out = s;
     return true;
 }
 
 // what the host reads after a search (pinned, host-coherent memory written over PCIe by one lane)
-__device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const CandRec* best, int status)
+// `bad`: the alphabet flag when the caller has it already (>= 0), else it is loaded here
+__device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const CandRec* best, int status, int bad = -1)
 {
     const bool is_max = a.is_max != 0;
     psa_result r;
@@ -1590,36 +1692,45 @@ __device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const Ca
         x.shard = status ? -2 - status : a.record_shard;
         *a.record_out = x;
     }
-    publish_tail(a.out, r, load_agent(a.bad), status, a.seq);
+    publish_tail(a.out, r, bad >= 0 ? bad : load_agent(a.bad), status, a.seq);
 }
 
 // ---- end of a single search inside the count kernel ---------------------------------
 // Run by the last tile workgroup to arrive (all of its waves).  The candidate list is complete and the bound in
 // global_best final: candidates it rules out are dropped, the survivors (a handful) are re-scored in the reference's
-// summation order — every wave of the workgroup classifies, then one wave per candidate walks — folded in the
-// is_swapable order and the tail is written.  More survivors than waves, or a Seq2 whose codes do not fit the LDS:
-// status 2, the host launches psa_rescore_kernel on the untouched lists.
+// summation order and folded in the is_swapable order, the tail is written.  Up to kFusedRound survivors at a time:
+//   pass 1  every thread classifies its 16-char segments of every survivor (codes into LDS, best delta rank and its first
+//           char, the segments' class counts), wave scans of the counts; spare threads fill the rounded-class-value table
+//   pass 2  block prefix of the counts, the certificate's first level (a thread per segment)
+//   pass 3  the certificate's second level (a 16-lane row per unsettled segment); the head chain of survivor j on wave
+//           WAVES - 1 - j beside it
+//   pass 4  one wave per survivor: true additions compacted, events prepared and applied (cert2_sum; walk_sum if that
+//           declines)
+// four workgroup barriers per round.  More survivors than kFusedMax, or a Seq2 whose codes do not fit the LDS: status 2,
+// the host launches psa_rescore_kernel on the untouched lists.
 constexpr int kFusedMax = 16;
 constexpr int kFusedWaves = 16;
-// LDS in front of the candidates' class codes (finish_search's carve-up) and how many candidates' codes fit at a time
-constexpr int kFusedFixedBytes = 2 * kRow * kRow + (8 + kMaxRanks) * (int)sizeof(double) +
-                                 kFusedWaves * (int)sizeof(WalkScratch) + kFusedMax * kFusedWaves * 8 +
-                                 kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4 + 16 + kFusedWaves * 8;
-// LDS of one candidate: its class codes + the walk's over-read, the certificate's prefix counts and bit mask
+constexpr int kFusedRound = 4;            // survivors of one round (their per-thread state is kept in registers)
+// LDS in front of the candidates' class codes (finish_search's carve-up) and how many candidates' regions fit at a time
+constexpr int kFusedFixedBytes = (2 * kRow * kRow + (8 + kMaxRanks) * (int)sizeof(double) +
+                                  kFusedWaves * (int)sizeof(WalkScratch) + 2 * kFusedRound * kFusedWaves * 8 +
+                                  kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4 + 16 + (int)sizeof(Cert2Table) + 15) & ~15;
+// LDS of one candidate: its class codes + the walk's over-read, then the certificate's data (Seq2 below 65,536 chars)
 __host__ __device__ inline int fused_codes_bytes(int m) { return (m + 64 * kRescoreEpl + 16 + 15) & ~15; }
+__host__ __device__ inline int fused_region_bytes(int m) { return fused_codes_bytes(m) + (m < 65536 ? cert2_layout(m).bytes : 0); }
 __host__ __device__ inline int fused_candidates_at_a_time(int lds_bytes, int m)
 {
-    const int region = fused_codes_bytes(m) + cert_bytes();
-    const int g = (lds_bytes - kFusedFixedBytes) / region;
-    return g > kFusedWaves ? kFusedWaves : g;
+    const int g = (lds_bytes - kFusedFixedBytes) / fused_region_bytes(m);
+    return g > kFusedRound ? kFusedRound : g;
 }
 
 template <int WAVES, bool RAW>
 __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned char* lds, int lds_bytes, int tid)
 {
-    static_assert(WAVES <= kFusedMax, "one walking wave per survivor of a round");
-    static_assert(sizeof(WalkScratch) % 16 == 0 && sizeof(CandRec) == 24, "LDS carve-up below");
+    static_assert(WAVES == kFusedWaves && kFusedRound <= WAVES && kMaxRanks == 16, "kFusedFixedBytes is this carve-up for 16 waves");
+    static_assert(sizeof(WalkScratch) % 16 == 0 && sizeof(CandRec) == 24 && sizeof(Cert2Table) % 8 == 0, "LDS carve-up below");
     constexpr int T = WAVES * 64;
+    static_assert(T >= 4 * kCert2Rows, "the table is filled by the workgroup's last threads");
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* p = lds;
@@ -1628,23 +1739,27 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     double* s_class = reinterpret_cast<double*>(p);                           p += 8 * sizeof(double);
     double* s_delta = reinterpret_cast<double*>(p);                           p += kMaxRanks * sizeof(double);
     WalkScratch* s_walk = reinterpret_cast<WalkScratch*>(p);                  p += WAVES * sizeof(WalkScratch);
-    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(p);    p += kFusedMax * WAVES * 8;   // [candidate of the round][wave]
+    unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(p);    p += kFusedRound * WAVES * 8;   // [candidate of the round][wave]
+    unsigned long long* s_wsum = reinterpret_cast<unsigned long long*>(p);    p += kFusedRound * WAVES * 8;   // the same shape: wave totals of the counts
     CandRec* s_rec = reinterpret_cast<CandRec*>(p);                           p += kFusedMax * sizeof(CandRec);
     int* s_surv = reinterpret_cast<int*>(p);                                  p += kFusedMax * 4;
     int* s_n = reinterpret_cast<int*>(p);                                     p += 16;
-    unsigned long long* s_wsum = reinterpret_cast<unsigned long long*>(p);    p += WAVES * 8;
-    unsigned char* s_codes = p;
+    Cert2Table* s_tab = reinterpret_cast<Cert2Table*>(p);
+    unsigned char* s_codes = lds + kFusedFixedBytes;
     const int m = r.m;
+    const bool certify = r.certify != 0;                                      // (host: only for m < 65,536)
     const int codes_bytes = fused_codes_bytes(m);
-    const int region = codes_bytes + cert_bytes();                           // per candidate: codes, true-addition list
-    static_assert(WAVES == kFusedWaves && kMaxRanks == 16, "kFusedFixedBytes is this carve-up for 16 waves");
-    const int G = fused_candidates_at_a_time(lds_bytes, m);                  // candidates classified at a time
+    const int region = fused_region_bytes(m);                                 // per candidate: codes, certificate
+    const Cert2Layout L = cert2_layout(m < 65536 ? m : 0);
+    const int G = fused_candidates_at_a_time(lds_bytes, m);                   // candidates of a round
 
     PSA_FPHASE(0);
     // ---- everything the tail reads from memory before it knows the survivors, in flight together: the search scalars,
-    // the whole candidate list (entries behind the count are never looked at) and the small tables
+    // the alphabet flag (every tile and converter has arrived: it is final), the whole candidate list (entries behind
+    // the count are never looked at) and the small tables
     const int count = load_agent(r.cand_count);
     const unsigned long long best_key = load_agent(r.global_best);
+    const int bad_flag = load_agent(r.bad);
     double up[2];
     int off[2];
 #pragma unroll
@@ -1660,11 +1775,12 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
 #pragma unroll
         for (int k = 0; k < 8; ++k) s_class[k] = r.class_value[k];
         s_n[0] = 0;
+        s_tab->tie = 0ull;
     }
     if (count > r.cap) {
         // overflow against the running bound: the bound stays in global_best, the host selects once more against it
         if (tid == 0) {
-            write_search_tail(r, nullptr, 1);
+            write_search_tail(r, nullptr, 1, bad_flag);
             store_agent(r.cand_count, 0);
             store_agent(r.done, 0);
         }
@@ -1680,35 +1796,99 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         }
     __syncthreads();
     PSA_FPHASE(1);
+    // (the rounded-class-value table: by the workgroup's last threads, which have the fewest segments; pass 4 reads it)
+    if (certify && tid >= T - 4 * kCert2Rows) cert2_fill_table(s_tab, s_class, r.fast_min_exp, tid - (T - 4 * kCert2Rows));
     const int nsurv = s_n[0];
     if (nsurv > kFusedMax || G < 1 || r.cap > 2 * T) {
         if (tid == 0) {
-            write_search_tail(r, nullptr, 2);
+            write_search_tail(r, nullptr, 2, bad_flag);
             store_agent(r.done, 0);                      // psa_rescore_kernel counts its own arrivals in it
         }
         return;
     }
+#ifdef PSA_TAIL_TWICE       // timing experiment: the rounds run twice, the stamps are the second (instruction-cache-warm) run's
+    for (int rep = 0; rep < 2; ++rep) {
+    __syncthreads();
+    PSA_FPHASE(1);
+#endif
     for (int base = 0; base < nsurv; base += G) {
         const int cnt = nsurv - base < G ? nsurv - base : G;
-        for (int j = 0; j < cnt; ++j) {
-            unsigned long long key = 0ull;
-            classify_chars<RAW>(r.s1 + s_surv[base + j], r.s2, s_clsrank, s_codes + (size_t)j * region, 0, m, tid, T, key,
-                                r.n1 - s_surv[base + j], m);
-            key = wave_max_u64(key);
-            if (lane == 0) s_keys[j * WAVES + wave] = key;
+        // ---- pass 1
+        unsigned long long mine[kFusedRound], excl[kFusedRound];
+#pragma unroll
+        for (int j = 0; j < kFusedRound; ++j) {
+            mine[j] = excl[j] = 0ull;
+            if (j < cnt) {
+                unsigned char* codes = s_codes + (size_t)j * region;
+                unsigned char* cert = codes + codes_bytes;
+                const int o = s_surv[base + j];
+                if (certify) {
+                    // bitmap and summary lie side by side: one clearing loop
+                    unsigned* bitmap = reinterpret_cast<unsigned*>(cert + L.bitmap);
+                    const int words = (L.summary - L.bitmap) / 4 + kCert2Summary;
+                    for (int w = tid; w < words; w += T) bitmap[w] = 0u;
+                    if (tid == 0) reinterpret_cast<Cert2Head*>(cert)->nfail = 0;
+                }
+                unsigned long long key = 0ull;
+                mine[j] = cert2_classify<T, RAW>(r.s1 + o, r.s2, s_clsrank, codes, m,
+                                                 certify ? reinterpret_cast<unsigned long long*>(cert + L.seg_before) : nullptr,
+                                                 reinterpret_cast<unsigned*>(cert + L.segbits), tid, key, r.n1 - o, m);
+#ifdef PSA_PHASE_TIMING
+                if (tid == 0) g_phase_ts[1005][3] = wall_clock64();
+#endif
+                key = wave_max_u64(key);
+                if (lane == 0) s_keys[j * WAVES + wave] = key;
+                if (certify) {
+                    const unsigned long long incl = (unsigned long long)wave_scan_inclusive((long long)mine[j]);
+                    excl[j] = incl - mine[j];
+                    if (lane == 63) s_wsum[j * WAVES + wave] = incl;
+                }
+#ifdef PSA_PHASE_TIMING
+                if (tid == 0) g_phase_ts[1005][4] = wall_clock64();
+                if (tid == T - 1) g_phase_ts[1005][5] = wall_clock64();
+#endif
+            }
         }
         __syncthreads();
         PSA_FPHASE(2);
-        if (r.certify)
+        // ---- pass 2
+        if (certify) {
+#pragma unroll
+            for (int j = 0; j < kFusedRound; ++j)
+                if (j < cnt) {
+                    unsigned char* codes = s_codes + (size_t)j * region;
+                    unsigned char* cert = codes + codes_bytes;
+                    unsigned long long before = excl[j], all = 0ull;
+#pragma unroll
+                    for (int w = 0; w < WAVES; ++w) {
+                        const unsigned long long x = s_wsum[j * WAVES + w];
+                        if (w < wave) before += x;
+                        all += x;
+                    }
+                    if (tid == 0) reinterpret_cast<Cert2Head*>(cert)->total = all;
+                    cert2_level1<T>(codes, m, s_class, r.walk_slack, r.fast_min_exp, cert, before, tid);
+                }
+            __syncthreads();
+            PSA_FPHASE(3);
+            // ---- pass 3
             for (int j = 0; j < cnt; ++j) {
-                unsigned char* mine = s_codes + (size_t)j * region;
-                certify_chars<T>(mine, m, s_class, r.walk_slack, r.fast_min_exp,
-                                 reinterpret_cast<CertList*>(mine + codes_bytes), s_wsum, tid);
+                unsigned char* codes = s_codes + (size_t)j * region;
+                unsigned char* cert = codes + codes_bytes;
+                cert2_level2<T>(codes, m, s_class, r.walk_slack, r.fast_min_exp, cert, tid);
+                if (wave == WAVES - 1 - j) {
+                    // the first chars: a plain chain (cpu_funcs.c:278), lanes past the end hold +0.0
+                    const int head_n = m < kCertChain ? m : kCertChain;
+                    const double hs = chain64(0.0, lane < head_n ? s_class[codes[lane] & 7u] : 0.0);
+                    if (lane == 0) reinterpret_cast<Cert2Head*>(cert)->head_sum = hs;
+                }
             }
-        PSA_FPHASE(3);
+            __syncthreads();
+        }
+        PSA_FPHASE(4);
+        // ---- pass 4
         if (wave < cnt) {
             const int o = s_surv[base + wave];
-            unsigned char* mine = s_codes + (size_t)wave * region;
+            unsigned char* codes = s_codes + (size_t)wave * region;
             // the best delta rank and its first char; the two symbols there are asked for now and used after the sum
             unsigned long long key = lane < WAVES ? s_keys[wave * WAVES + lane] : 0ull;
             key = wave_max_u64(key);
@@ -1718,10 +1898,8 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
             if constexpr (RAW) { sym2 = ascii_code(sym2); sym1 = ascii_code(sym1); }
             WalkStats st = {0, 0, 0};
             double s = 0.0;
-            if (!r.certify ||
-                !certified_sum(mine, m, s_class, reinterpret_cast<CertList*>(mine + codes_bytes),
-                               cert_true_additions(reinterpret_cast<const CertList*>(mine + codes_bytes)), &s_walk[wave], lane, s))
-                s = walk_sum(0.0, mine, 0, m, s_class, &s_walk[wave], r.fast_ok, r.fast_min_exp, lane, st);
+            if (!certify || !cert2_sum(codes, m, s_class, codes + codes_bytes, s_tab, lane, s))
+                s = walk_sum(0.0, codes, 0, m, s_class, &s_walk[wave], r.fast_ok, r.fast_min_exp, lane, st);
             if (lane == 0) {
                 CandRec c;
                 c.offset = o;
@@ -1738,10 +1916,12 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
                 s_rec[base + wave] = c;
             }
         }
-        PSA_FPHASE(4);
         __syncthreads();
         PSA_FPHASE(5);
     }
+#ifdef PSA_TAIL_TWICE
+    }
+#endif
     if (tid == 0) {
         const bool is_max = r.is_max != 0;
         int idx = -1;
@@ -1751,9 +1931,9 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
                 idx = k;
         if (idx >= 0) {
             const CandRec b = s_rec[idx];
-            write_search_tail(r, &b, 0);
+            write_search_tail(r, &b, 0, bad_flag);
         } else {
-            write_search_tail(r, nullptr, 0);
+            write_search_tail(r, nullptr, 0, bad_flag);
         }
         // the search scalars are clean for the next search on this slot
         store_agent(r.cand_count, 0);
@@ -1762,7 +1942,11 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     }
     PSA_FPHASE(6);
 #ifdef PSA_PHASE_TIMING
-    if (tid == 0) { g_phase_ts[1003][0] = (unsigned long long)count; g_phase_ts[1003][1] = (unsigned long long)nsurv; g_phase_ts[1003][2] = (unsigned long long)reinterpret_cast<const CertList*>(s_codes + codes_bytes)->nev; }
+    if (tid == 0) {
+        g_phase_ts[1003][0] = (unsigned long long)count;
+        g_phase_ts[1003][1] = (unsigned long long)nsurv;
+        g_phase_ts[1003][2] = certify ? (unsigned long long)reinterpret_cast<const Cert2Head*>(s_codes + codes_bytes)->nfail : 0ull;
+    }
 #endif
 }
 
@@ -2414,7 +2598,11 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     __shared__ double             s_class[8];     // the class values, indexable (a by-value kernel argument indexed
                                                   // at run time would be copied to scratch by every lane)
     __shared__ unsigned long long s_key[kRescoreThreads / 64];
-    __shared__ CertList           s_cert;                                       // certified_sum: the true additions
+    // the certificate of a Seq2 that is staged whole (m <= kRescoreChunk): cert2_layout(kRescoreChunk) bytes
+    constexpr int kCertBytes = ((int)sizeof(Cert2Head) + 8 * (kRescoreChunk / kCertSeg + 1) + 4 * (kRescoreChunk / kCertSeg + 2) +
+                                4 * (kRescoreChunk / 32 + 2) + 4 * kCert2Summary + 2 * kCert2MaxFail + 2 * kCert2MaxEv + 15) & ~15;
+    __shared__ __attribute__((aligned(16))) unsigned char s_cert[kCertBytes];
+    __shared__ Cert2Table         s_tab;
     __shared__ unsigned long long s_wsum[kRescoreThreads / 64];
     __shared__ int s_last;
     extern __shared__ unsigned char s_pad[];      // never touched: only makes the workgroup too big to share a
@@ -2458,8 +2646,12 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) s_class[k] = a.class_value[k];
+        s_tab.tie = 0ull;
     }
     __syncthreads();
+    static_assert(kRescoreThreads >= 4 * kCert2Rows, "the table is filled by the workgroup's last threads");
+    if (a.certify && tid >= kRescoreThreads - 4 * kCert2Rows)       // (read behind the barriers of the first candidate's passes)
+        cert2_fill_table(&s_tab, s_class, a.fast_min_exp, tid - (kRescoreThreads - 4 * kCert2Rows));
     const double final_best = key_order(*a.global_best);
     PSA_RPHASE(1);
     for (int ci = blockIdx.x; ci < count; ci += gridDim.x) {
@@ -2474,19 +2666,62 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     unsigned long long key = 0ull;  // per thread: max of (rank << 32 | ~i): best rank, then lowest i
     WalkStats st = {0, 0, 0};
 
+    if (a.certify && m <= kRescoreChunk) {
+        // ---- the whole Seq2 is staged: classification + certificate in the passes of finish_search (one candidate),
+        // the certified sum on wave 0, the head chain on the last wave beside level 2
+        static_assert(kRescoreChunk < 65536, "cert2_layout");
+        const Cert2Layout L = cert2_layout(m);
+        Cert2Head* head = reinterpret_cast<Cert2Head*>(s_cert);
+        {
+            unsigned* bitmap = reinterpret_cast<unsigned*>(s_cert + L.bitmap);
+            const int words = (L.summary - L.bitmap) / 4 + kCert2Summary;
+            for (int w = tid; w < words; w += kRescoreThreads) bitmap[w] = 0u;
+            if (tid == 0) head->nfail = 0;
+        }
+        const unsigned long long mine = cert2_classify<kRescoreThreads, false>(
+            s1, a.s2, s_clsrank, s_codes, m, reinterpret_cast<unsigned long long*>(s_cert + L.seg_before),
+            reinterpret_cast<unsigned*>(s_cert + L.segbits), tid, key, 0, 0);
+        const unsigned long long incl = (unsigned long long)wave_scan_inclusive((long long)mine);
+        if (lane == 63) s_wsum[tid >> 6] = incl;
+        __syncthreads();
+        if (ci == (int)blockIdx.x) PSA_RPHASE(2);
+        {
+            unsigned long long before = incl - mine, all = 0ull;
+#pragma unroll
+            for (int w = 0; w < kRescoreThreads / 64; ++w) {
+                const unsigned long long x = s_wsum[w];
+                if (w < (tid >> 6)) before += x;
+                all += x;
+            }
+            if (tid == 0) head->total = all;
+            cert2_level1<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, s_cert, before, tid);
+        }
+        __syncthreads();
+        cert2_level2<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, s_cert, tid);
+        if ((tid >> 6) == kRescoreThreads / 64 - 1) {
+            const int head_n = m < kCertChain ? m : kCertChain;
+            const double hs = chain64(0.0, lane < head_n ? s_class[s_codes[lane] & 7u] : 0.0);
+            if (lane == 0) head->head_sum = hs;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            if (!cert2_sum(s_codes, m, s_class, s_cert, &s_tab, lane, s)) {
+                st.left += 1000;                        // (phase-timing builds: the walk was needed)
+                s = walk_sum(0.0, s_codes, 0, m, s_class, &s_walk, a.fast_ok, a.fast_min_exp, lane, st);
+            }
+        }
+        if (ci == (int)blockIdx.x) PSA_RPHASE(3);
+        __syncthreads();            // the next candidate overwrites the staged codes
+    } else
     for (int c0 = 0; c0 < m; c0 += kRescoreChunk) {
         const int c1 = c0 + kRescoreChunk < m ? c0 + kRescoreChunk : m;
         classify_chars(s1, a.s2, s_clsrank, s_codes, c0, c1, tid, kRescoreThreads, key);
         __syncthreads();
         if (ci == (int)blockIdx.x) PSA_RPHASE(2);
-        // ---- sum the chunk in reference order (wave 0): certified segments when the whole Seq2 is staged, else the walk
-        const bool certify = a.certify && m <= kRescoreChunk;
-        if (certify) certify_chars<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, &s_cert, s_wsum, tid);
+        // ---- sum the chunk in reference order (wave 0): the integer walk, the plain chain where that does not apply
         if (tid < 64) {
-            if (!certify || !certified_sum(s_codes, m, s_class, &s_cert, cert_true_additions(&s_cert), &s_walk, lane, s)) {
-                st.left += 1000;                        // (phase-timing builds: the walk was needed)
-                s = walk_sum(s, s_codes, c0, c1, s_class, &s_walk, a.fast_ok, a.fast_min_exp, lane, st);
-            }
+            st.left += 1000;
+            s = walk_sum(s, s_codes, c0, c1, s_class, &s_walk, a.fast_ok, a.fast_min_exp, lane, st);
         }
         if (ci == (int)blockIdx.x) PSA_RPHASE(3);
         __syncthreads();            // the next chunk overwrites s_codes

@@ -40,6 +40,22 @@ ACGT = [
     ("acgt_max", None, None, 1000000, 10000, W_README, True),
     ("acgt_min", None, None, 1000000, 10000, W_README, False),
 ]
+# --protein: a protein-like input at full size: the 20 amino-acid letters with their natural frequencies (Robinson &
+# Robinson percentages), numpy default_rng(5): Seq1 first, then Seq2 — bench.py's `low_entropy_protein` leg and the GPU test
+PROTEIN = [
+    ("protein_max", "protein", None, 1000000, 10000, W_README, True),
+    ("protein_min", "protein", None, 1000000, 10000, W_README, False),
+]
+PROTEIN_LETTERS = b"ARNDCQEGHILKMFPSTWYV"
+PROTEIN_PERCENT = [7.8, 5.1, 4.5, 5.4, 1.9, 4.3, 6.3, 7.4, 2.2, 5.1, 9.1, 5.7, 2.2, 3.9, 5.2, 7.1, 5.8, 1.3, 3.2, 6.4]
+
+
+def protein_pair(n, m):
+    import numpy as np
+    rng = np.random.default_rng(5)
+    ab = np.frombuffer(PROTEIN_LETTERS, np.uint8)
+    p = np.asarray(PROTEIN_PERCENT) / np.sum(PROTEIN_PERCENT)
+    return rng.choice(ab, n, p=p).tobytes(), rng.choice(ab, m, p=p).tobytes()
 
 
 def acgt_pair(n, m):
@@ -51,15 +67,18 @@ def acgt_pair(n, m):
 
 def main():
     out_path = os.path.join(ROOT, "tests", "golden", "synthetic_golden.json")
-    cases = (CASES if "--acgt" not in sys.argv else []) + (FULL if "--full" in sys.argv else []) + \
-            (ACGT if "--acgt" in sys.argv else [])
+    special = "--acgt" in sys.argv or "--protein" in sys.argv
+    cases = ([] if special else CASES) + (FULL if "--full" in sys.argv else []) + \
+            (ACGT if "--acgt" in sys.argv else []) + (PROTEIN if "--protein" in sys.argv else [])
     old = {}
     if os.path.exists(out_path):
         old = {c["name"]: c for c in json.load(open(out_path))["cases"]}
     done = []
     threads = os.cpu_count() or 1
     for name, seed1, seed2, n, m, w, is_max in cases:
-        if seed1 is None:
+        if seed1 == "protein":
+            s1, s2 = protein_pair(n, m)
+        elif seed1 is None:
             s1, s2 = acgt_pair(n, m)
         else:
             s1 = psa_amd.generate_sequence(seed1, n)

@@ -81,22 +81,27 @@ for row in tail:     # the workgroup that finished the search (finish_search)
 
 full = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
 ft, fc = full[1002], full[1003]
-names = ["arrival -> count + lists filtered", "tables + classify (all waves)", "certificate (all waves)",
-         "sum (one wave per survivor)", "barrier", "fold + tail"]
-print(f"fused tail of the last search: {fc[0]} candidates listed, {fc[1]} survive the final bound, {fc[2]} true additions "
-      f"behind the first 64 chars of survivor 0")
+names = ["arrival -> lists filtered, table", "pass 1: classify + counts (all waves)", "pass 2: block prefix + level 1",
+         "pass 3: level 2 | head chain", "pass 4: sum (one wave per survivor)", "fold + tail"]
+print(f"fused tail of the last search: {fc[0]} candidates listed, {fc[1]} survive the final bound, {fc[2]} segments of "
+      f"survivor 0 went to level 2")
 for k, name in enumerate(names):
     print(f"tail {name:36s} {(ft[k + 1] - ft[k]) / 100.0:7.2f} us")
 
+p1 = full[1005]
+if p1[0] > 0:
+    print(f"pass 1 (wave 0): tail phase-1 stamp -> loads issued {(p1[0] - ft[1]) / 100.0:.2f} us; loads returned +{(p1[1] - p1[0]) / 100.0:.2f}; "
+          f"lookups + codes stored +{(p1[2] - p1[1]) / 100.0:.2f}; segment done, padding +{(p1[3] - p1[2]) / 100.0:.2f}; wave max + scan "
+          f"+{(p1[4] - p1[3]) / 100.0:.2f}; last wave there {(p1[5] - ft[1]) / 100.0:.2f} us after the phase-1 stamp")
 st = full[1004]
-for k, name in enumerate(["sort the true additions", "head: 64 chars as a plain chain", "events prepared (a lane each)", "events applied in order"]):
+for k, name in enumerate(["true additions compacted from the bitmap", "counts at the head", "events prepared (first 64)", "events applied (to the end)"]):
     print(f"sum  {name:36s} {(st[k + 1] - st[k]) / 100.0:7.2f} us")
 
 # re-score kernel (workgroup 0, its first candidate)
 ctx.debug_rescore(np.array([r.offset, 5, 77777], dtype=np.int32))
 assert lib.psa_debug_phase_ts(buf) == 0
 ts = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)[1000]
-names = ["start -> tables + scalars", "classify (all waves)", "walk (wave 0)", "key reduce + record", "arrive + fold + tail"]
+names = ["start -> tables + scalars", "classify + counts (all waves)", "certificate + sum (wave 0)", "key reduce + record", "arrive + fold + tail"]
 for k, name in enumerate(names):
     print(f"rescore {name:28s} {(ts[k + 1] - ts[k]) / 100.0:7.2f} us")
 walk = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8)[1001]
