@@ -955,7 +955,10 @@ def main():
         torch.cuda.empty_cache()
         group = run_group_leg(args, world)
         line["c_abi_group"] = group
-        if not group.get("ok", False):
+        # On one GPU this leg is deterministic and tested (its failure is a bug: the run fails).  With N > 1 it is the
+        # first time the library's RCCL exchange meets real hardware: a problem there is reported in the object
+        # ("ok": false, "error") but does not take the N-rank headline measurement down with it.
+        if not group.get("ok", False) and world == 1:
             failed = True
     if rank == 0:
         print(json.dumps(line), flush=True)

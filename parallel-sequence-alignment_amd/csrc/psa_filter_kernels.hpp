@@ -1305,7 +1305,7 @@ constexpr int kCert2Rows = 48;            // binades of the rounded-class-value 
 
 struct Cert2Table {                       // per search
     long long rt[kCert2Rows][4];
-    unsigned long long tie;               // bit row: an addend ties in that binade (round-half-even: the walk's business)
+    unsigned tie[kCert2Rows];             // != 0: an addend ties in that binade (round-half-even: the walk's business); a byte per class
     int emin, pad;
 };
 struct Cert2Head {                        // per candidate
@@ -1333,12 +1333,12 @@ __host__ __device__ inline Cert2Layout cert2_layout(int m)
 }
 static_assert(sizeof(Cert2Head) == 24, "cert2_layout");
 
-// the table (any kCert2Rows * 4 threads; `idx` = this thread's entry).  tie bits are or-ed in: zero `tie` first.
-__device__ __forceinline__ void cert2_fill_table(Cert2Table* tb, const double* s_class, int fast_min_exp, int idx)
+// the table (any kCert2Rows * 4 threads; `idx` = this thread's entry, `value` = that class's pair score)
+__device__ __forceinline__ void cert2_fill_table(Cert2Table* tb, double value, int fast_min_exp, int idx)
 {
     const int row = idx >> 2, c = idx & 3;
     const int e = fast_min_exp + row;
-    const unsigned long long pb = (unsigned long long)__double_as_longlong(s_class[c]);
+    const unsigned long long pb = (unsigned long long)__double_as_longlong(value);
     const int ep = (int)((pb >> 52) & 0x7ff);
     long long r = 0;
     bool tie = false;
@@ -1354,15 +1354,10 @@ __device__ __forceinline__ void cert2_fill_table(Cert2Table* tb, const double* s
         }
     }
     tb->rt[row][c] = r;
-    if (tie) atomicOr(&tb->tie, 1ull << row);
+    reinterpret_cast<unsigned char*>(tb->tie)[idx] = tie ? 1 : 0;
     if (idx == 0) tb->emin = fast_min_exp;
 }
 
-// ---- pass 1 (every thread): the thread's 16-char segments of one candidate -------------------------------------------
-// classifies them (class | rank codes into LDS, `key` = max(rank << 32 | ~i) as classify_chars), counts their classes
-// (returned: all of the thread's segments together, 16 bits per class) and leaves the per-segment counts where pass 2
-// finds them (seg_before[seg] = the counts of the thread's segments in front of `seg`).  Segments behind m are padding
-// (class 4: the walk's over-read and level 2's rows read up to 528 chars behind m).
 // class counts (16 bits per class) of the first `r` chars of a segment from its class bits
 __device__ __forceinline__ unsigned long long cert2_counts_of_bits(unsigned bits, int r)
 {
@@ -1373,6 +1368,10 @@ __device__ __forceinline__ unsigned long long cert2_counts_of_bits(unsigned bits
     return (unsigned long long)(n0 | (n1 << 16)) | ((unsigned long long)(n2 | (n3 << 16)) << 32);
 }
 
+// Returns the WAVE's class counts in front of this thread's first segment + the thread's own (an inclusive wave scan of
+// the threads' counts; lane 63 holds the wave's total): seg_before[] is left relative to the wave's first segment, pass
+// 2 adds the waves in front.  The code is kept SMALL (the four dwords of a segment in a rolled loop): the tail runs once
+// per search on a workgroup whose instruction cache holds the count loop — every byte of it is a cold fetch.
 template <int NT, bool RAW>
 __device__ __forceinline__ unsigned long long cert2_classify(const unsigned char* __restrict__ s1, const unsigned char* __restrict__ s2,
                                                              const unsigned char* s_clsrank, unsigned char* s_codes, int m,
@@ -1384,6 +1383,7 @@ __device__ __forceinline__ unsigned long long cert2_classify(const unsigned char
     const int per = (nseg + NT - 1) / NT;                    // 1 up to 16,384 chars with 1,024 threads
     const int per_pad = per + (nseg_pad - nseg + NT - 1) / NT;
     unsigned long long mine = 0ull;
+#pragma unroll 1
     for (int q = 0; q < per_pad; ++q) {
         const int seg = q < per ? tid * per + q : nseg + (q - per) * NT + tid;      // real segments first, then the padding's
         const int k0 = seg * kCertSeg;
@@ -1402,8 +1402,9 @@ __device__ __forceinline__ unsigned long long cert2_classify(const unsigned char
             if (tid == 0) g_phase_ts[1005][1] = wall_clock64();
 #endif
             // per char: one table byte (class | rank << 3; chars behind m come out as class 4, rank 0 by themselves), its
-            // place in the packed codes, the running best (rank, lowest char) and the two class bits — 32-bit ops only
-            unsigned packed[4], b0 = 0u, b1 = 0u, best = 0u;
+            // place in the packed codes and the two class bits; the best (rank, lowest char) of the segment is taken from
+            // the packed codes four chars at a time (bytes rank << 4 | 15 - t, maxima as 16-bit pairs) — 32-bit ops only
+            unsigned packed[4], b0 = 0u, b1 = 0u;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 packed[x] = 0u;
@@ -1412,13 +1413,27 @@ __device__ __forceinline__ unsigned long long cert2_classify(const unsigned char
                     const int t = 4 * x + j;
                     const unsigned cr = s_clsrank[((w2[x] >> (8 * j)) & 0xffu) * kRow + ((w1[x] >> (8 * j)) & 0xffu)];
                     packed[x] |= cr << (8 * j);
-                    const unsigned cand = ((cr >> 3) << 4) | (unsigned)(15 - t);
-                    best = cand > best ? cand : best;
                     b0 |= (cr & 1u) << t;
                     b1 |= ((cr >> 1) & 1u) << t;
                 }
             }
             *reinterpret_cast<uint4*>(s_codes + k0) = make_uint4(packed[0], packed[1], packed[2], packed[3]);
+            unsigned best;
+            {
+                // byte t of v[x]: rank << 4 | 15 - t (ranks are 4 bits: kMaxRanks = 16)
+                typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+                auto pk_max = [](unsigned a, unsigned b) {
+                    const u16x2 r = __builtin_elementwise_max(__builtin_bit_cast(u16x2, a), __builtin_bit_cast(u16x2, b));
+                    return __builtin_bit_cast(unsigned, r);
+                };
+                unsigned mx = 0u;
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    const unsigned v = ((packed[x] << 1) & 0xf0f0f0f0u) | (0x0c0d0e0fu - 0x04040404u * (unsigned)x);
+                    mx = pk_max(mx, pk_max(v & 0x00ff00ffu, (v >> 8) & 0x00ff00ffu));
+                }
+                best = (mx & 0xffffu) > (mx >> 16) ? (mx & 0xffffu) : (mx >> 16);
+            }
 #ifdef PSA_PHASE_TIMING
             if (tid == 0) g_phase_ts[1005][2] = wall_clock64();
 #endif
@@ -1429,18 +1444,32 @@ __device__ __forceinline__ unsigned long long cert2_classify(const unsigned char
                 const int valid = m - k0 < kCertSeg ? m - k0 : kCertSeg;
                 const unsigned bits = b0 | (b1 << 16);
                 segbits[seg] = bits;
-                seg_before[seg] = mine;                      // (made absolute by cert2_level1, behind the scan's barrier)
+                if (per > 1) seg_before[seg] = mine;         // (relative to the thread's first segment: see below)
                 mine += cert2_counts_of_bits(bits, valid);
             }
         } else if (q >= per && seg < nseg_pad) {
             *reinterpret_cast<uint4*>(s_codes + k0) = make_uint4(0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u);
         }
     }
-    return mine;
+    if (!seg_before) return 0ull;
+    const unsigned long long incl = (unsigned long long)wave_scan_inclusive((long long)mine);
+    const unsigned long long excl = incl - mine;
+    // seg_before relative to the wave's first segment: one store for a thread's one segment (Seq2 up to 16,384 chars with
+    // 1,024 threads), otherwise the thread's segments again (its own stores, no barrier needed)
+    if (per == 1) {
+        if (tid < nseg) seg_before[tid] = excl;
+    } else if (excl != 0ull) {
+#pragma unroll 1
+        for (int q = 0; q < per; ++q) {
+            const int seg = tid * per + q;
+            if (seg < nseg) seg_before[seg] += excl;
+        }
+    }
+    return incl;
 }
 
 // ---- pass 2 (every thread, behind the barrier that follows the block scan's wave totals) ----------------------------
-// `before` = class counts in front of the thread's first segment (block scan of cert2_classify's return values).
+// `before` = class counts of the WAVES in front of this thread's (their totals: lane 63 of cert2_classify's result).
 // Level 1: all prefix sums of a segment lie within A = sum |p_i| of the sum in front of it; that sum A + slack inside its
 // binade settles the segment.  The others go to fail[].  head->nfail must be zero (and the bitmap clear) by now.
 template <int NT>
@@ -1617,7 +1646,7 @@ __device__ __forceinline__ bool cert2_sum(const unsigned char* s_codes, int m, c
                 const unsigned key = (unsigned)((unsigned long long)__double_as_longlong(cert_value(ca, s_class)) >> 52);
                 const int e = (int)(key & 0x7ffu);
                 const int row = e - tb->emin;
-                if (row < 0 || row >= kCert2Rows || ((tb->tie >> (row & 63)) & 1ull)) bad = true;
+                if (row < 0 || row >= kCert2Rows || tb->tie[row] != 0u) bad = true;
                 else {
                     unsigned long long delta = 0ull;
 #pragma unroll
@@ -1724,6 +1753,11 @@ __host__ __device__ inline int fused_candidates_at_a_time(int lds_bytes, int m)
     return g > kFusedRound ? kFusedRound : g;
 }
 
+// where finish_search keeps its survivor counter (the caller zeroes it BEFORE the arrival's barrier, so the survivors can
+// be collected without a barrier of their own)
+constexpr int kFusedCounterOffset = 2 * kRow * kRow + (8 + kMaxRanks) * (int)sizeof(double) + kFusedWaves * (int)sizeof(WalkScratch) +
+                                    2 * kFusedRound * kFusedWaves * 8 + kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4;
+
 template <int WAVES, bool RAW>
 __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned char* lds, int lds_bytes, int tid)
 {
@@ -1743,7 +1777,7 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     unsigned long long* s_wsum = reinterpret_cast<unsigned long long*>(p);    p += kFusedRound * WAVES * 8;   // the same shape: wave totals of the counts
     CandRec* s_rec = reinterpret_cast<CandRec*>(p);                           p += kFusedMax * sizeof(CandRec);
     int* s_surv = reinterpret_cast<int*>(p);                                  p += kFusedMax * 4;
-    int* s_n = reinterpret_cast<int*>(p);                                     p += 16;
+    int* s_n = reinterpret_cast<int*>(p);                                     p += 16;   // (= lds + kFusedCounterOffset, zero on entry)
     Cert2Table* s_tab = reinterpret_cast<Cert2Table*>(p);
     unsigned char* s_codes = lds + kFusedFixedBytes;
     const int m = r.m;
@@ -1774,8 +1808,12 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) s_class[k] = r.class_value[k];
-        s_n[0] = 0;
-        s_tab->tie = 0ull;
+    }
+    // (the rounded-class-value table, by the workgroup's last threads while the loads above are in flight; pass 4 reads it)
+    if (certify && tid >= T - 4 * kCert2Rows) {
+        const int idx = tid - (T - 4 * kCert2Rows), c = idx & 3;
+        const double value = c == 0 ? r.class_value[0] : c == 1 ? r.class_value[1] : c == 2 ? r.class_value[2] : r.class_value[3];
+        cert2_fill_table(s_tab, value, r.fast_min_exp, idx);
     }
     if (count > r.cap) {
         // overflow against the running bound: the bound stays in global_best, the host selects once more against it
@@ -1786,7 +1824,6 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         }
         return;
     }
-    __syncthreads();
     const double final_best = key_order(best_key);
 #pragma unroll
     for (int e = 0; e < 2; ++e)
@@ -1796,8 +1833,6 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         }
     __syncthreads();
     PSA_FPHASE(1);
-    // (the rounded-class-value table: by the workgroup's last threads, which have the fewest segments; pass 4 reads it)
-    if (certify && tid >= T - 4 * kCert2Rows) cert2_fill_table(s_tab, s_class, r.fast_min_exp, tid - (T - 4 * kCert2Rows));
     const int nsurv = s_n[0];
     if (nsurv > kFusedMax || G < 1 || r.cap > 2 * T) {
         if (tid == 0) {
@@ -1814,60 +1849,50 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     for (int base = 0; base < nsurv; base += G) {
         const int cnt = nsurv - base < G ? nsurv - base : G;
         // ---- pass 1
-        unsigned long long mine[kFusedRound], excl[kFusedRound];
-#pragma unroll
-        for (int j = 0; j < kFusedRound; ++j) {
-            mine[j] = excl[j] = 0ull;
-            if (j < cnt) {
-                unsigned char* codes = s_codes + (size_t)j * region;
-                unsigned char* cert = codes + codes_bytes;
-                const int o = s_surv[base + j];
-                if (certify) {
-                    // bitmap and summary lie side by side: one clearing loop
-                    unsigned* bitmap = reinterpret_cast<unsigned*>(cert + L.bitmap);
-                    const int words = (L.summary - L.bitmap) / 4 + kCert2Summary;
-                    for (int w = tid; w < words; w += T) bitmap[w] = 0u;
-                    if (tid == 0) reinterpret_cast<Cert2Head*>(cert)->nfail = 0;
-                }
-                unsigned long long key = 0ull;
-                mine[j] = cert2_classify<T, RAW>(r.s1 + o, r.s2, s_clsrank, codes, m,
-                                                 certify ? reinterpret_cast<unsigned long long*>(cert + L.seg_before) : nullptr,
-                                                 reinterpret_cast<unsigned*>(cert + L.segbits), tid, key, r.n1 - o, m);
-#ifdef PSA_PHASE_TIMING
-                if (tid == 0) g_phase_ts[1005][3] = wall_clock64();
-#endif
-                key = wave_max_u64(key);
-                if (lane == 0) s_keys[j * WAVES + wave] = key;
-                if (certify) {
-                    const unsigned long long incl = (unsigned long long)wave_scan_inclusive((long long)mine[j]);
-                    excl[j] = incl - mine[j];
-                    if (lane == 63) s_wsum[j * WAVES + wave] = incl;
-                }
-#ifdef PSA_PHASE_TIMING
-                if (tid == 0) g_phase_ts[1005][4] = wall_clock64();
-                if (tid == T - 1) g_phase_ts[1005][5] = wall_clock64();
-#endif
+#pragma unroll 1
+        for (int j = 0; j < cnt; ++j) {
+            unsigned char* codes = s_codes + (size_t)j * region;
+            unsigned char* cert = codes + codes_bytes;
+            const int o = s_surv[base + j];
+            unsigned long long key = 0ull;
+            const unsigned long long incl =
+                cert2_classify<T, RAW>(r.s1 + o, r.s2, s_clsrank, codes, m,
+                                       certify ? reinterpret_cast<unsigned long long*>(cert + L.seg_before) : nullptr,
+                                       reinterpret_cast<unsigned*>(cert + L.segbits), tid, key, r.n1 - o, m);
+            if (certify) {
+                // (level 2 sets the bits, behind two barriers) bitmap and summary lie side by side: one clearing loop
+                unsigned* bitmap = reinterpret_cast<unsigned*>(cert + L.bitmap);
+                const int words = (L.summary - L.bitmap) / 4 + kCert2Summary;
+                for (int w = tid; w < words; w += T) bitmap[w] = 0u;
+                if (tid == 0) reinterpret_cast<Cert2Head*>(cert)->nfail = 0;
             }
+#ifdef PSA_PHASE_TIMING
+            if (tid == 0) g_phase_ts[1005][3] = wall_clock64();
+#endif
+            key = wave_max_u64(key);
+            if (lane == 0) s_keys[j * WAVES + wave] = key;
+            if (lane == 63) s_wsum[j * WAVES + wave] = incl;
+#ifdef PSA_PHASE_TIMING
+            if (tid == 0) g_phase_ts[1005][4] = wall_clock64();
+            if (tid == T - 1) g_phase_ts[1005][5] = wall_clock64();
+#endif
         }
         __syncthreads();
         PSA_FPHASE(2);
         // ---- pass 2
         if (certify) {
-#pragma unroll
-            for (int j = 0; j < kFusedRound; ++j)
-                if (j < cnt) {
-                    unsigned char* codes = s_codes + (size_t)j * region;
-                    unsigned char* cert = codes + codes_bytes;
-                    unsigned long long before = excl[j], all = 0ull;
-#pragma unroll
-                    for (int w = 0; w < WAVES; ++w) {
-                        const unsigned long long x = s_wsum[j * WAVES + w];
-                        if (w < wave) before += x;
-                        all += x;
-                    }
-                    if (tid == 0) reinterpret_cast<Cert2Head*>(cert)->total = all;
-                    cert2_level1<T>(codes, m, s_class, r.walk_slack, r.fast_min_exp, cert, before, tid);
-                }
+#pragma unroll 1
+            for (int j = 0; j < cnt; ++j) {
+                unsigned char* codes = s_codes + (size_t)j * region;
+                unsigned char* cert = codes + codes_bytes;
+                // the waves' totals: lane w holds wave w's; an exclusive scan gives the counts in front of every wave
+                const unsigned long long tot = lane < WAVES ? s_wsum[j * WAVES + lane] : 0ull;
+                const unsigned long long scan = (unsigned long long)wave_scan_inclusive((long long)tot);
+                const unsigned long long before = (unsigned long long)readlane64((long long)(scan - tot), wave);
+                const unsigned long long all = (unsigned long long)readlane64((long long)scan, WAVES - 1);
+                if (tid == 0) reinterpret_cast<Cert2Head*>(cert)->total = all;
+                cert2_level1<T>(codes, m, s_class, r.walk_slack, r.fast_min_exp, cert, before, tid);
+            }
             __syncthreads();
             PSA_FPHASE(3);
             // ---- pass 3
@@ -2353,6 +2378,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     // barrier, then ONE lane's arrival; the last arriver acquires.
     __shared__ int s_last_tile;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (finish_search's survivor counter: the plane rows / exchange area it lies in are dead since the counter sums)
+    if (tid == 0) *reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + kFusedCounterOffset) = 0;
     __syncthreads();
     if (tid == 0) {
         const int arrived = __hip_atomic_fetch_add(a.tail.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2646,12 +2673,14 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) s_class[k] = a.class_value[k];
-        s_tab.tie = 0ull;
+    }
+    static_assert(kRescoreThreads >= 4 * kCert2Rows, "the table is filled by the workgroup's last threads");
+    if (a.certify && tid >= kRescoreThreads - 4 * kCert2Rows) {     // (read behind the barriers of the first candidate's passes)
+        const int idx = tid - (kRescoreThreads - 4 * kCert2Rows), c = idx & 3;
+        const double value = c == 0 ? a.class_value[0] : c == 1 ? a.class_value[1] : c == 2 ? a.class_value[2] : a.class_value[3];
+        cert2_fill_table(&s_tab, value, a.fast_min_exp, idx);
     }
     __syncthreads();
-    static_assert(kRescoreThreads >= 4 * kCert2Rows, "the table is filled by the workgroup's last threads");
-    if (a.certify && tid >= kRescoreThreads - 4 * kCert2Rows)       // (read behind the barriers of the first candidate's passes)
-        cert2_fill_table(&s_tab, s_class, a.fast_min_exp, tid - (kRescoreThreads - 4 * kCert2Rows));
     const double final_best = key_order(*a.global_best);
     PSA_RPHASE(1);
     for (int ci = blockIdx.x; ci < count; ci += gridDim.x) {
@@ -2678,21 +2707,19 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
             for (int w = tid; w < words; w += kRescoreThreads) bitmap[w] = 0u;
             if (tid == 0) head->nfail = 0;
         }
-        const unsigned long long mine = cert2_classify<kRescoreThreads, false>(
+        const unsigned long long incl = cert2_classify<kRescoreThreads, false>(
             s1, a.s2, s_clsrank, s_codes, m, reinterpret_cast<unsigned long long*>(s_cert + L.seg_before),
             reinterpret_cast<unsigned*>(s_cert + L.segbits), tid, key, 0, 0);
-        const unsigned long long incl = (unsigned long long)wave_scan_inclusive((long long)mine);
         if (lane == 63) s_wsum[tid >> 6] = incl;
         __syncthreads();
         if (ci == (int)blockIdx.x) PSA_RPHASE(2);
         {
-            unsigned long long before = incl - mine, all = 0ull;
-#pragma unroll
-            for (int w = 0; w < kRescoreThreads / 64; ++w) {
-                const unsigned long long x = s_wsum[w];
-                if (w < (tid >> 6)) before += x;
-                all += x;
-            }
+            constexpr int kWaves = kRescoreThreads / 64;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const unsigned long long tot = lane < kWaves ? s_wsum[lane] : 0ull;
+            const unsigned long long scan = (unsigned long long)wave_scan_inclusive((long long)tot);
+            const unsigned long long before = (unsigned long long)readlane64((long long)(scan - tot), wave);
+            const unsigned long long all = (unsigned long long)readlane64((long long)scan, kWaves - 1);
             if (tid == 0) head->total = all;
             cert2_level1<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, s_cert, before, tid);
         }
