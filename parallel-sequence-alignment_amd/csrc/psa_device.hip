@@ -395,6 +395,7 @@ struct SearchSlot {
     unsigned long long* d_partial = nullptr;   size_t partial_cap = 0;   // [nchunks][span_pad] counts of a multi-chunk search
     int*                d_arrivals = nullptr;  int arrivals_cap = 0;     // [ntiles], zero between searches
     Scalars*            d_scal = nullptr;
+    unsigned long long* d_best_split = nullptr;   // kBestSplit words of the running bound, a cache line each (zero between searches)
     int*                d_cand = nullptr;
     double*             d_cand_upper = nullptr;
     psa::CandRec*       d_rec = nullptr;
@@ -1162,6 +1163,7 @@ psa::RescoreArgs rescore_args(const psa_context* c, const SearchSlot& s, long lo
     r.cand = s.d_cand;
     r.cand_upper = s.inline_select ? s.d_cand_upper : nullptr;
     r.global_best = &s.d_scal->global_best;
+    r.best_split = nullptr;                   // (launch_count: single searches that end inside the count kernel)
     r.cand_count = &s.d_scal->cand_count;
     r.rec = s.d_rec;
     r.done = &s.d_scal->done;
@@ -1327,6 +1329,9 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.tail = rescore_args(c, s, (long long)span * s.m, ts);
     a.tail.record_out = c->record_out;
     a.tail.record_shard = c->record_shard;
+#ifndef PSA_NO_BEST_SPLIT          // (A/B builds: the running bound in one word, as until round 3)
+    if (fused && s.d_scal == c->slot[0].d_scal) a.tail.best_split = c->slot[0].d_best_split;     // (a slot's own scalars, not a pool entry)
+#endif
     a.raw1 = a.raw2 = nullptr;
     a.classes_w = nullptr;
     a.bad = c->d_bad;
@@ -1681,9 +1686,10 @@ psa_status psa_create(int device, void* stream, psa_context** out)
             const size_t o_bad = take(sizeof(int));
             const size_t o_ctl = take(128);
             const size_t o_rawarr = take(64);
-            size_t o_scal[kSlots], o_cand[kSlots], o_upper[kSlots], o_rec[kSlots];
+            size_t o_scal[kSlots], o_split[kSlots], o_cand[kSlots], o_upper[kSlots], o_rec[kSlots];
             for (int k = 0; k < kSlots; ++k) {
                 o_scal[k] = take(sizeof(Scalars));
+                o_split[k] = take(sizeof(unsigned long long) * psa::kBestSplit * psa::kBestStride);
                 o_cand[k] = take(sizeof(int) * kCandCap);
                 o_upper[k] = take(sizeof(double) * kCandCap);
                 o_rec[k] = take(sizeof(psa::CandRec) * kCandCap);
@@ -1705,6 +1711,7 @@ psa_status psa_create(int device, void* stream, psa_context** out)
             for (int k = 0; k < kSlots; ++k) {
                 SearchSlot& sl = c->slot[k];
                 sl.d_scal = reinterpret_cast<Scalars*>(d + o_scal[k]);
+                sl.d_best_split = reinterpret_cast<unsigned long long*>(d + o_split[k]);
                 sl.d_cand = reinterpret_cast<int*>(d + o_cand[k]);
                 sl.d_cand_upper = reinterpret_cast<double*>(d + o_upper[k]);
                 sl.d_rec = reinterpret_cast<psa::CandRec*>(d + o_rec[k]);
@@ -1950,7 +1957,10 @@ static psa_status search_async_impl(psa_context* c, int first, int last, psa_res
     if (c->pending_filter) {
         // the search's last workgroup leaves the scalars zeroed; only a search that was enqueued but never
         // waited for, failed or fell back can have left them dirty
-        if (s.scal_dirty) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
+        if (s.scal_dirty) {
+            PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
+            PSA_HIP(hipMemsetAsync(s.d_best_split, 0, sizeof(unsigned long long) * psa::kBestSplit * psa::kBestStride, c->stream));
+        }
         s.scal_dirty = true;
         c->select_frozen_next = c->select_frozen;      // (debug library; the re-selection of settle_search runs normally)
         PSA_TRY(enqueue_filter_search(c, first, last, c->profiling));
@@ -2117,7 +2127,10 @@ psa_status psa_search_device(psa_context* c, const void* d_seq1, int n, const vo
     c->record_out = nullptr;
     c->record_shard = -1;
     c->last_kernel_queries = 1;
-    if (s.scal_dirty) PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
+    if (s.scal_dirty) {
+        PSA_HIP(hipMemsetAsync(s.d_scal, 0, sizeof(Scalars), c->stream));
+        PSA_HIP(hipMemsetAsync(s.d_best_split, 0, sizeof(unsigned long long) * psa::kBestSplit * psa::kBestStride, c->stream));
+    }
     s.scal_dirty = true;
     const RawSequences raw = {static_cast<const unsigned char*>(d_seq1), n, static_cast<const unsigned char*>(d_seq2), m};
     const psa_status launched = launch_filter_front(c, s, plan, first, last, c->stream, false, primary_tables(c), nullptr, nullptr,

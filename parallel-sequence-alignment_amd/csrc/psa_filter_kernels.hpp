@@ -937,6 +937,13 @@ struct RescoreArgs {
     const int*           cand;
     const double*        cand_upper;  // optimistic bounds of the candidates, or NULL (already filtered)
     unsigned long long*  global_best; // final best pessimistic bound (ordered-u64)
+    // Single searches that end inside the count kernel keep the RUNNING bound in kBestSplit words (a tile uses word
+    // tile % kBestSplit, kBestStride words apart: a cache line each): all 244 tiles of a 1M x 10k search reach their
+    // atomicMax within 0.3 us of each other, and 244 atomics on one word were served one after the other (1.7 us for the
+    // last arrivers against 0.3 uncontended).  A tile then knows the bounds of its own word's tiles only — a weaker
+    // lower bound, a few more listed candidates, the same survivors (whoever re-scores re-checks against the final bound =
+    // max of the words and of global_best).  NULL: one word (batches, searches a second launch finishes).
+    unsigned long long*  best_split;
     int*                 cand_count;
     CandRec*             rec;       // [cap]
     int*                 done;      // arrival counter of the candidate workgroups
@@ -965,6 +972,8 @@ struct RescoreArgs {
 #ifndef PSA_RESCORE_EPL
 #define PSA_RESCORE_EPL 8
 #endif
+constexpr int kBestSplit = 8;           // words of the split running bound
+constexpr int kBestStride = 16;         // u64 between them (128 bytes)
 constexpr int kRescoreEpl = PSA_RESCORE_EPL;   // chars per lane and batch on the integer walk
 constexpr int kRescoreThreads = 512;
 constexpr int kRescoreChunk = 32768;    // chars whose class codes are staged in LDS at a time
@@ -1791,9 +1800,17 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     // ---- everything the tail reads from memory before it knows the survivors, in flight together: the search scalars,
     // the alphabet flag (every tile and converter has arrived: it is final), the whole candidate list (entries behind
     // the count are never looked at) and the small tables
-    const int count = load_agent(r.cand_count);
-    const unsigned long long best_key = load_agent(r.global_best);
-    const int bad_flag = load_agent(r.bad);
+    // The search's scalars by ONE 8-byte load per wave, a lane each: lanes 0..7 the words of the running bound, lane 8
+    // global_best, lane 9 the candidate count (and the arrival counter behind it), lanes 10.. the alphabet flag (every
+    // tile and converter has arrived: it is final).  (Every lane loading every scalar was 13 requests per wave to the
+    // same few lines: the 16 waves' 200 requests queued for 2 us.)
+    static_assert(kBestSplit == 8, "lane map of the scalar load");
+    const unsigned long long* scalar_at =
+        lane < kBestSplit ? (r.best_split ? r.best_split + lane * kBestStride : r.global_best)
+        : lane == 8       ? r.global_best
+        : lane == 9       ? reinterpret_cast<const unsigned long long*>(r.cand_count)
+                          : reinterpret_cast<const unsigned long long*>(r.bad);
+    const unsigned long long scalar = load_agent(scalar_at);
     double up[2];
     int off[2];
 #pragma unroll
@@ -1815,13 +1832,19 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         const double value = c == 0 ? r.class_value[0] : c == 1 ? r.class_value[1] : c == 2 ? r.class_value[2] : r.class_value[3];
         cert2_fill_table(s_tab, value, r.fast_min_exp, idx);
     }
+    const int count = __builtin_amdgcn_readlane((int)scalar, 9);
+    const int bad_flag = __builtin_amdgcn_readlane((int)scalar, 10);
+    const unsigned long long best_key = wave_max_u64(lane <= kBestSplit ? scalar : 0ull);      // the final bound
     if (count > r.cap) {
         // overflow against the running bound: the bound stays in global_best, the host selects once more against it
         if (tid == 0) {
             write_search_tail(r, nullptr, 1, bad_flag);
             store_agent(r.cand_count, 0);
             store_agent(r.done, 0);
+            __hip_atomic_store(r.global_best, best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        // (every word of the split bound: the re-selection launch's tiles then select against the final bound at once)
+        if (r.best_split && tid < kBestSplit) __hip_atomic_store(r.best_split + tid * kBestStride, best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     const double final_best = key_order(best_key);
@@ -1838,7 +1861,9 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         if (tid == 0) {
             write_search_tail(r, nullptr, 2, bad_flag);
             store_agent(r.done, 0);                      // psa_rescore_kernel counts its own arrivals in it
+            __hip_atomic_store(r.global_best, best_key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ... and reads the final bound here
         }
+        if (r.best_split && tid < kBestSplit) __hip_atomic_store(r.best_split + tid * kBestStride, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
 #ifdef PSA_TAIL_TWICE       // timing experiment: the rounds run twice, the stamps are the second (instruction-cache-warm) run's
@@ -1965,6 +1990,7 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         store_agent(r.done, 0);
         __hip_atomic_store(r.global_best, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (r.best_split && tid < kBestSplit) __hip_atomic_store(r.best_split + tid * kBestStride, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     PSA_FPHASE(6);
 #ifdef PSA_PHASE_TIMING
     if (tid == 0) {
@@ -2351,8 +2377,20 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         // keeps a superset of the true candidates (whoever re-scores re-checks against the final bound)
         unsigned long long key = s_best[tid][0];
         for (int w = 1; w < WAVES; ++w) key = s_best[tid][w] > key ? s_best[tid][w] : key;
-        const unsigned long long old = atomicMax(a.sel[tid].global_best, key);
+#ifdef PSA_PHASE_TIMING
+        if (tid == 0 && blockIdx.x < 244) g_phase_ts[700 + blockIdx.x][0] = wall_clock64();
+#endif
+        unsigned long long old;
+        if (a.fused && a.tail.best_split) {
+            // (fused: one mode.  In a re-selection launch every word starts from the first pass's final bound.)
+            old = atomicMax(a.tail.best_split + (tile_x & (kBestSplit - 1)) * kBestStride, key);
+        } else {
+            old = atomicMax(a.sel[tid].global_best, key);
+        }
         s_best[tid][WAVES] = old > key ? old : key;
+#ifdef PSA_PHASE_TIMING
+        if (tid == 0 && blockIdx.x < 244) g_phase_ts[700 + blockIdx.x][1] = wall_clock64();
+#endif
     }
     __syncthreads();
     for (int mode = 0; mode < a.nmodes; ++mode) {
@@ -2382,8 +2420,14 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     if (tid == 0) *reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + kFusedCounterOffset) = 0;
     __syncthreads();
     if (tid == 0) {
+#ifdef PSA_PHASE_TIMING
+        if (blockIdx.x < 244) g_phase_ts[700 + blockIdx.x][2] = wall_clock64();
+#endif
         const int arrived = __hip_atomic_fetch_add(a.tail.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last_tile = arrived == ntiles_x - 1;
+#ifdef PSA_PHASE_TIMING
+        if (blockIdx.x < 244) { g_phase_ts[700 + blockIdx.x][3] = wall_clock64(); g_phase_ts[700 + blockIdx.x][4] = (unsigned long long)arrived; }
+#endif
         if (s_last_tile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     __syncthreads();

@@ -88,6 +88,15 @@ print(f"fused tail of the last search: {fc[0]} candidates listed, {fc[1]} surviv
 for k, name in enumerate(names):
     print(f"tail {name:36s} {(ft[k + 1] - ft[k]) / 100.0:7.2f} us")
 
+at = full[700:700 + min(len(ts), 244)]
+if at[:, 0].max() > 0:
+    d_max = (at[:, 1] - at[:, 0]) / 100.0
+    d_arr = (at[:, 3] - at[:, 2]) / 100.0
+    order = np.argsort(at[:, 4])
+    print(f"atomicMax on the running bound, per workgroup: mean {d_max.mean():.2f} min {d_max.min():.2f} max {d_max.max():.2f} us; "
+          f"arrival atomic: mean {d_arr.mean():.2f} min {d_arr.min():.2f} max {d_arr.max():.2f} us; the last 8 arrivers' "
+          f"atomicMax {np.round(d_max[order[-8:]], 2).tolist()} arrival {np.round(d_arr[order[-8:]], 2).tolist()}; "
+          f"arrival times of the last 8 relative to the last: {np.round((at[order[-8:], 2] - at[order[-1], 2]) / 100.0, 2).tolist()}")
 p1 = full[1005]
 if p1[0] > 0:
     print(f"pass 1 (wave 0): tail phase-1 stamp -> loads issued {(p1[0] - ft[1]) / 100.0:.2f} us; loads returned +{(p1[1] - p1[0]) / 100.0:.2f}; "
