@@ -426,7 +426,11 @@ __global__ __launch_bounds__(256) void psa_encode_pair_streamed_kernel(PrepareAr
     report_done(done);
 }
 
-// out[b] bit t = in[t] bit b  (recursive block swap, Hacker's Delight 7-3, mirrored)
+// out[b] bit t = in[t] bit b  (recursive block swap, Hacker's Delight 7-3, mirrored).  A butterfly of stage j exchanges
+// the high j-bit halves of a with the low halves of b inside every 2j-bit block:
+//     a' = (a & ~(m << j)) | ((b & m) << j)        b' = (b & ~m) | ((a >> j) & m)
+// = one shift + one v_bitop3_b32 ("c ? b : a", 0xd8) each: 4 full-rate instructions.  (Written as xor swaps the compiler
+// spent 4.8 per butterfly, 52 of them half-rate v_bfi_b32: the plane build is VALU-bound, 463 instructions per slot.)
 __device__ __forceinline__ void transpose32(unsigned (&a)[32])
 {
     unsigned m = 0x0000ffffu;
@@ -434,9 +438,9 @@ __device__ __forceinline__ void transpose32(unsigned (&a)[32])
     for (int j = 16; j != 0; j >>= 1, m ^= (m << j)) {
 #pragma unroll
         for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
-            const unsigned t = ((a[k] >> j) ^ a[k + j]) & m;
-            a[k] ^= t << j;
-            a[k + j] ^= t;
+            const unsigned x = a[k], y = a[k + j];
+            a[k] = __builtin_amdgcn_bitop3_b32(x, y << j, m << j, 0xd8);
+            a[k + j] = __builtin_amdgcn_bitop3_b32(y, x >> j, m, 0xd8);
         }
     }
 }
@@ -639,9 +643,9 @@ __device__ __forceinline__ void planes_to_counts(unsigned (&a)[16])
     for (int j = 8; j != 0; j >>= 1, m ^= (m << j)) {
 #pragma unroll
         for (int k = 0; k < 16; k = (k + j + 1) & ~j) {
-            const unsigned t = ((a[k] >> j) ^ a[k + j]) & m;
-            a[k] ^= t << j;
-            a[k + j] ^= t;
+            const unsigned x = a[k], y = a[k + j];              // (butterflies as in transpose32: shift + select)
+            a[k] = __builtin_amdgcn_bitop3_b32(x, y << j, m << j, 0xd8);
+            a[k + j] = __builtin_amdgcn_bitop3_b32(y, x >> j, m, 0xd8);
         }
     }
 }

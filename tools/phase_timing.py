@@ -54,7 +54,7 @@ buf = (C.c_ulonglong * (1024 * 8))()
 lib.psa_debug_phase_ts.restype = C.c_int
 assert lib.psa_debug_phase_ts(buf) == 0
 ts = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8).astype(np.int64)
-nt = 1000          # rows 1000.. hold the tail's and the re-score kernel's stamps
+nt = 300           # rows 300.. hold other stamps (raw converters, batch kernel, atomics at 700.., tail and re-score at 1000..)
 ts = ts[:nt]
 ts = ts[ts[:, 0] > 0]
 t0 = ts[:, 0].min()
