@@ -28,7 +28,7 @@ for blk in re.split(r"remark: [^\n]*Function Name: ", usage)[1:]:
     out.append(" | ".join([short, f("VGPRs"), f("AGPRs"), f("TotalSGPRs"), f("SGPRs Spill"), f("VGPRs Spill"),
                            f(r"ScratchSize \[bytes/lane\]"), f(r"Occupancy \[waves/SIMD\]"), f(r"LDS Size \[bytes/block\]")]))
 out.append("")
-out.append("# main loops (basic blocks with > 300 v_bitop3_b32): VALU instructions, and spill / scratch code inside them")
+out.append("# main loops (basic blocks with > 400 v_bitop3_b32): VALU instructions, and spill / scratch code inside them")
 for kern in ("_ZN3psa16psa_count_kernelILi16ELb0EEEvNS_9CountArgsE", "_ZN3psa16psa_count_kernelILi16ELb1EEEvNS_9CountArgsE",
              "_ZN3psa20psa_count_duo_kernelENS_7DuoArgsE"):
     i = asm.index(kern + ":")
@@ -47,7 +47,7 @@ for kern in ("_ZN3psa16psa_count_kernelILi16ELb0EEEvNS_9CountArgsE", "_ZN3psa16p
     short = ("psa_count_kernel<16, raw>" if "ELb1" in kern else "psa_count_kernel<16>") if "count_kernelILi16" in kern else "psa_count_duo_kernel" 
     for name, b in blocks:
         nb = sum("v_bitop3" in l for l in b)
-        if nb > 300:
+        if nb > 400:
             valu = sum(l.strip().startswith("v_") for l in b)
             lanes = sum("v_readlane" in l or "v_writelane" in l for l in b)
             scratch = sum("scratch_" in l for l in b)
