@@ -5,7 +5,7 @@ for rep in 1 2 3; do
 for spec in "$@"; do
   v=${spec%%:*}; envs=""
   if [[ "$spec" == *:* ]]; then envs=$(echo "${spec#*:}" | tr ',' ' '); fi
-  env $envs PSA_AMD_LIB=$LIBDIR/libpsa_$v.so python bench.py --no-cpu-baseline --steps 3 2>/dev/null > /tmp/ab.json
+  env $envs PSA_AMD_LIB=$LIBDIR/libpsa_$v.so python bench.py --no-cpu-baseline --no-extras --no-group-leg --steps 3 2>/dev/null > /tmp/ab.json
   python - "$spec" <<'PY'
 import json,sys
 d=json.load(open("/tmp/ab.json"))
