@@ -565,14 +565,17 @@ def main():
     if world > 1 and args.mode == "batch" and not emulated:
         s_lo, s_hi = psa.shard_range(total, world, rank)
         nb = min(64, nq)
+        # every rank searches its shard of the SAME queries (seeds 2002..; the weak-scaling batch gave each rank its own)
+        sq = tq if not weak else torch.from_numpy(
+            np.stack([psa.generate_sequence_np(SEED_QUERY0 + q, m) for q in range(nb)])).to(device)
 
         def shard_one():
-            rec = ctx.search_device(t1.data_ptr(), n, tq[0].data_ptr(), m, s_lo, s_hi)
+            rec = ctx.search_device(t1.data_ptr(), n, sq[0].data_ptr(), m, s_lo, s_hi)
             return exchange_and_fold_many(psa, dist, torch, [rec], rank, world, True, xdev)
 
         def shard_many():
             ctx.set_seq1_device(t1.data_ptr(), n)
-            recs = ctx.search_batch_device(tq.data_ptr(), nb, m, m, s_lo, s_hi)
+            recs = ctx.search_batch_device(sq.data_ptr(), nb, m, m, s_lo, s_hi)
             return exchange_and_fold_many(psa, dist, torch, recs, rank, world, True, xdev)
         shard_one()
         one_steps = 20
@@ -950,7 +953,7 @@ def main():
     if dist:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0 and not args.no_group_leg and not emulated and not args.share_gpu:
+    if rank == 0 and not args.no_group_leg and not emulated:
         del t1, tq
         torch.cuda.empty_cache()
         group = run_group_leg(args, world)

@@ -337,6 +337,28 @@ void init_trace(const char* stage)
 inline void init_trace(const char*) {}
 #endif
 
+// debug library, PSA_TRACE_SEARCH=1: host-side stamps of one blocking search (printed by psa_search_wait)
+#ifdef PSA_EXPERIMENT
+struct SearchTrace {
+    bool on = std::getenv("PSA_TRACE_SEARCH") != nullptr;
+    std::chrono::steady_clock::time_point t[8];
+    void stamp(int k) { if (on) t[k] = std::chrono::steady_clock::now(); }
+    void print() const
+    {
+        if (!on) return;
+        auto us = [&](int a, int b) { return std::chrono::duration<double, std::micro>(t[b] - t[a]).count(); };
+        std::fprintf(stderr, "[psa search] entry->planned %.2f, ->args built %.2f, launch call %.2f, ->wait entered %.2f, tail seen after %.2f, settle %.2f us\n",
+                     us(0, 1), us(1, 2), us(2, 3), us(3, 4), us(4, 5), us(5, 6));
+    }
+};
+SearchTrace g_search_trace;
+#define PSA_STRACE(k) g_search_trace.stamp(k)
+#define PSA_STRACE_PRINT() g_search_trace.print()
+#else
+#define PSA_STRACE(k) do { } while (0)
+#define PSA_STRACE_PRINT() do { } while (0)
+#endif
+
 // The library selects the device of the context it works on; an entry point puts the caller's current device back
 // when it returns (a host program with its own HIP / torch work on another GPU keeps launching there).
 struct DeviceScope {
@@ -1389,9 +1411,11 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
         c->granted16 = kLdsLimit;
     }
+    PSA_STRACE(2);
     hipLaunchKernelGGL(psa::psa_count_kernel<16>, grid, dim3(16 * 64), p.lds_bytes, stream, a);
     c->last_kernel = "psa_count_kernel<16>";
     PSA_HIP(hipGetLastError());
+    PSA_STRACE(3);
     return PSA_OK;
 }
 
@@ -1928,6 +1952,7 @@ static psa_status enqueue_filter_search(psa_context* c, int first, int last, boo
     SearchSlot& s = c->slot[0];
     FilterPlan plan;
     PSA_TRY(plan_on_slot(s, first, last, c->stream, &plan));
+    PSA_STRACE(1);
     const bool fused = psa::fused_candidates_at_a_time(plan.lds_bytes, s.m) >= 1;
     PSA_TRY(launch_filter_front(c, s, plan, first, last, c->stream, profile, primary_tables(c), nullptr, nullptr, fused));
     if (!fused) {
@@ -1940,6 +1965,7 @@ static psa_status enqueue_filter_search(psa_context* c, int first, int last, boo
 static psa_status search_async_impl(psa_context* c, int first, int last, psa_result* record_out, int record_shard)
 {
     if (!c) { set_last_error("context is NULL"); return PSA_ERR_ARG; }
+    PSA_STRACE(0);
     SearchSlot& s = c->slot[0];
     PSA_TRY(check_ready(c, s.m, first, last));
     DeviceScope device_scope;
@@ -2060,18 +2086,22 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
 {
     if (!c || !out) { set_last_error("psa_search_wait: NULL argument"); return PSA_ERR_ARG; }
     if (!c->pending) { set_last_error("psa_search_wait: no search in flight"); return PSA_ERR_STATE; }
+    PSA_STRACE(4);
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));                // (a group waits for several devices' searches in turn; the retry
                                               // paths launch kernels)
     if (c->profiling ||
         !tail_arrived(c, spin_budget_us(c, c->pending_first, c->pending_last, c->slot[0].m, c->pending_filter)))
         PSA_HIP(hipStreamSynchronize(c->stream));
+    PSA_STRACE(5);
     c->pending = false;
     const psa_status st = settle_search(c);
     c->record_out = nullptr;
     c->record_shard = -1;
     PSA_TRY(st);
     *out = c->h_tails[0].result;
+    PSA_STRACE(6);
+    PSA_STRACE_PRINT();
     if (c->profiling && c->timing_valid) {
         float a = 0.f, b = 0.f;
         PSA_HIP(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));

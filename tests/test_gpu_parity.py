@@ -923,6 +923,9 @@ def test_bench_n_rank_paths_rehearsed_on_one_gpu(psa, extra):
     from conftest import ROOT
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--steps", "1",
            "--warmup", "1", "--queries", "16", "--no-cpu-baseline"] + extra
+    with_group_leg = extra == ["--scaling", "strong"]          # the c_abi_group child process behind an N-rank run: once
+    if not with_group_leg:
+        cmd.append("--no-group-leg")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     run = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert run.returncode == 0, run.stderr[-3000:]
@@ -934,6 +937,13 @@ def test_bench_n_rank_paths_rehearsed_on_one_gpu(psa, extra):
         assert v["query0_max_equals_golden"] and v["query0_min_equals_golden"] and v["batch_from_host_equals_batch"]
         assert v["batch_equals_single_search_queries"] > 0 and v["sequential_engine_fallbacks"] == 0
         assert line["config"]["queries_per_step"] == (32 if extra[1] == "weak" else 16)
+        # configs[3] inside the N-rank batch line: the offsets of query 0 sharded over the ranks, one exchange, fold
+        shard = line["offset_shard"]
+        assert shard["result_query0"] == {"offset": 870261, "score": -3265.7999999995977}
+        assert shard["in_flight_query0_equals_blocking"] and shard["blocking_search_us"] > 0
+    if with_group_leg:
+        group = line["c_abi_group"]
+        assert group["ok"] and all(g["ok"] for g in group["groups"]), group
 
 
 def test_bench_line_carries_the_contract(psa):
@@ -967,6 +977,15 @@ def test_bench_line_carries_the_contract(psa):
     assert d["sequential_engine"]["equals_filter_engine"]
     assert set(d["shard_emulation"]["blocking_search_us_per_rank"]) == {"1", "2", "4", "8"}
     assert d["low_entropy_acgt"]["max"]["fallbacks"] == 0 and d["low_entropy_acgt"]["min"]["fallbacks"] == 0
+    for leg in ("low_entropy_acgt", "low_entropy_protein"):        # within 1.25x of the uniform input (margin for noise)
+        for mode in ("max", "min"):
+            assert d[leg][mode]["ratio_to_uniform_a_z"] < 1.35 and d[leg][mode]["second_launches"] == 0, (leg, mode, d[leg][mode])
+    # the library's own multi-GPU path, driven by a child process: an RCCL group of the one device + 2 / 4 / 8 contexts with
+    # the host exchange; answers equal a single context's, and 8 devices' launches are issued side by side
+    group = d["c_abi_group"]
+    assert group["ok"] and [len(g["devices"]) for g in group["groups"]] == [1, 2, 4, 8]
+    assert all(g["sharded_search"]["equals_single_context"] and g["batch_sharded"]["256"]["equals_single_context"] for g in group["groups"])
+    assert group["groups"][3]["sharded_search"]["host_issue_us"] < 25.0
     assert d["value"] > 1e14 and d["timed_region_8d"]["value"] > 1e14
     assert d["single_search_latency_ms"] < 0.2 and d["gpu_run_program_latency_ms"] < 0.3
 
