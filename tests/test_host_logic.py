@@ -114,6 +114,22 @@ def test_only_the_c_abi_is_exported(psa):
     assert names == set(psa.EXPORTED_SYMBOLS) | {psa.CXX_GPU_RUN_PROGRAM}
 
 
+def test_test_hooks_live_in_the_debug_library_only(psa, psa_debug):
+    """psa_debug_counts / psa_debug_rescore are declared in include/psa_debug.h and exported by
+    libpsa_debug.so (-DPSA_EXPERIMENT) only; the product library's dynamic symbols are the reference boundary plus the
+    psa_* product calls (test_only_the_c_abi_is_exported)."""
+    import subprocess
+    header = open(os.path.join(ROOT, "include", "psa_debug.h")).read()
+    declared = set(re.findall(r"^\s*(?:psa_status|double|void|int|const char\*)\s+(\w+)\s*\(", header, re.M))
+    assert declared == set(psa.DEBUG_SYMBOLS)
+    out = subprocess.run(["nm", "-D", "--defined-only", psa_debug.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    names = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    assert names == set(psa.EXPORTED_SYMBOLS) | set(psa.DEBUG_SYMBOLS) | {psa.CXX_GPU_RUN_PROGRAM}
+    assert not any(hasattr(psa.lib, name) for name in psa.DEBUG_SYMBOLS)
+    with pytest.raises(psa.PsaError):                       # the binding says where the hook lives instead of crashing
+        psa.Context.debug_counts(object.__new__(psa.Context), 0, 1)
+
+
 def test_plain_symbol_detects_a_caller_with_other_array_limits(psa, tmp_path):
     """gpu_run_program by name reads the stock 10001 / 5001 layout.  A caller that binds it with this repo's
     1,000,001 / 10,001 struct (no psa.h) is told so: no NUL inside seq1[10001] -> message + exit(EXIT_FAILURE), like
