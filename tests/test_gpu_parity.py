@@ -436,6 +436,25 @@ def test_overflow_against_running_bound_is_reselected_not_sequential(psa, psa_de
         c.set_sequences(s1, s2)
         assert_same(c.search(40001, 58000), oracle.search(s1, s2, w, True, 40001, 58000, threads=8))
         assert (c.reselect_count(), c.fallback_count()) == (4, 0)
+    # the same through a device group (an RCCL group of the one device): the search's record comes back tagged "look
+    # again" and the device goes through the single-context retry path; a batch whose queries the host had to finish is
+    # copied into the exchange block again (the finishing kernels' records are stale)
+    with psa_debug.Group([0]) as g:
+        g.set_weights(w, True)
+        g.set_seq1(s1)
+        g.set_seq2(s2)
+        res, _ = g.search()
+        assert_same(res, want)
+        got = g.search_batch([s2, other, s2])
+        assert_same(got[0], want)
+        assert_same(got[1], want_other)
+        assert_same(got[2], want)
+    with psa_debug.Group([0, 0, 0], psa_debug.EXCHANGE_HOST) as g:
+        g.set_weights(w, True)
+        g.set_seq1(s1)
+        g.set_seq2(s2)
+        res, _ = g.search()
+        assert_same(res, want)
     monkeypatch.delenv("PSA_SELECT_FROZEN")
     with psa.Context(0) as c:
         c.set_engine(psa.ENGINE_FILTER)
@@ -1043,6 +1062,26 @@ def test_stock_reference_caller_links_and_runs(psa, oracle, reference_records, t
     run = subprocess.run([str(exe), os.path.join(GOLDEN, "reference_input.txt")], capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stderr
     assert run.stdout.splitlines() == lines
+
+
+@pytest.mark.parametrize("ndev", [1, 4])
+def test_group_api_from_c(psa, oracle, tmp_path, ndev):
+    """tests/c/group_caller.c: a plain C program (gcc, include/psa.h only) drives the device-group API — the reference's
+    MPI layer (cpu_funcs.c:49-94, 128-133) as one process: psa_group_create_ex, the setters, psa_search_sharded,
+    psa_group_last_timing, psa_search_batch_sharded — and checks the answers against a single context itself; the
+    answer it prints is the oracle's."""
+    import subprocess
+    from conftest import PKG, ROOT
+    exe = tmp_path / "group_caller"
+    lib_dir = os.path.join(PKG, "psa_amd")
+    subprocess.run(["gcc", "-O1", "-std=c11", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "c", "group_caller.c"), "-L", lib_dir, "-lpsa_amd", f"-Wl,-rpath,{lib_dir}"],
+                   check=True, capture_output=True, text=True)
+    run = subprocess.run([str(exe), str(ndev)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr
+    s1, s2 = psa.generate_sequence(11, 200000), psa.generate_sequence(12, 3000)
+    score, off, ci, ch = oracle.search(s1, s2, W_README, True, threads=8)
+    assert run.stdout.strip() == "ok %d %d %s %.17g" % (off, ci, ch, score)
 
 
 def test_filter_engine_synthetic_golden_and_ranges(psa, oracle):
