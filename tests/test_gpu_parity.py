@@ -601,6 +601,43 @@ def test_group_of_several_contexts_host_exchange(psa, oracle, reference_records,
             assert [key(r) for r in hi] == [key(r) for r in want_hi] and [key(r) for r in lo] == [key(r) for r in want_lo]
 
 
+def test_group_full_size_configs3_and_configs4(psa):
+    """BASELINE.json configs[3] and [4] at their stated sizes through the device group, as far as one GPU goes: 8
+    contexts on device 0 with the host exchange.  configs[3]: the 990,001 offsets of the 1M x 10k MAX search split by the
+    reference's rank rule (cpu_funcs.c:128-133), every shard issued by its launcher thread, fold (cpu_funcs.c:71-94) ==
+    the committed CPU-oracle golden, MIN as well; every shard record == a single context's search of that range.
+    configs[4]: 64 queries, MIN + MAX, dealt to the 8 contexts == a single context's batch."""
+    gold = {c["name"]: c for c in json.load(open(os.path.join(GOLDEN, "synthetic_golden.json")))["cases"]}
+    n, m = 1_000_000, 10_000
+    s1, s2 = psa.generate_sequence(1002, n), psa.generate_sequence(2002, m)
+    total = n - m + 1
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    with psa.Group([0] * 8, psa.EXCHANGE_HOST) as g, psa.Context(0) as c:
+        g.set_seq1(s1)
+        g.set_seq2(s2)
+        c.set_seq1(s1)
+        for is_max, name in ((True, "c3_max"), (False, "c3_min")):
+            g.set_weights(W_README, is_max)
+            res, shards = g.search()
+            gd = gold[name]
+            assert (res.offset, res.char_offset, chr(res.ch), "%.17g" % res.score) == (gd["offset"], gd["char_offset"], gd["ch"], gd["score"])
+            assert res.pairs == total * m
+            c.set_weights(W_README, is_max)
+            c.set_seq2(s2)
+            for r in range(8):
+                lo, hi = psa.shard_range(total, 8, r)
+                assert key(shards[r]) == key(c.search(lo, hi)) and shards[r].pairs == (hi - lo) * m, (name, r)
+        qs = [psa.generate_sequence(2002 + q, m) for q in range(64)]
+        g.set_weights(W_README, True)
+        c.set_weights(W_README, True)
+        hi_g, lo_g = g.search_batch(qs, minmax=True)
+        hi_c, lo_c = c.search_batch_minmax(qs)
+        assert [key(r) for r in hi_g] == [key(r) for r in hi_c] and [key(r) for r in lo_g] == [key(r) for r in lo_c]
+        assert [r.shard for r in hi_g] == list(range(64))
+        issue_us, total_us = g.last_timing()
+        assert 0.0 < issue_us <= total_us
+
+
 def test_single_search_is_one_launch_unless_too_many_survive(psa, oracle, reference_records):
     """A single filter search ends inside the count kernel: its last tile workgroup re-scores the survivors (<= 16, one
     wave each) and writes the tail.  Record 9 has 89 exact ties -> they all survive the final bound -> the tail asks
