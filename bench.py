@@ -628,7 +628,7 @@ def main():
     # VALU-issue-bound, so the difference is the clock (the shard_emulation leg, which runs behind other GPU work,
     # measures the same search a few microseconds faster for the same reason)
     search_only_warm_us = None
-    if qhi - qlo >= 2:
+    if qhi - qlo >= 2 and not args.no_extras:        # (profiling passes: no launches of another size in the counters' means)
         ctx.set_seq1_device(p1, n)
         for _ in range(3):
             ctx.search_batch_device(tq[qlo].data_ptr(), min(qhi - qlo, 64), m, m, lo1, hi1)

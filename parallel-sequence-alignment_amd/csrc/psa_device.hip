@@ -2755,8 +2755,15 @@ public:
             cv_.notify_all();
         }
         job(0);
-        for (int i = 1; i < n_; ++i)
-            while (done_[(size_t)i].v.load(std::memory_order_acquire) != g) __builtin_ia32_pause();
+        for (int i = 1; i < n_; ++i) {
+            // (a device's share of a blocking search ends within microseconds of the caller's own; a batch's may take
+            // milliseconds: after a short spin the caller gives its core up between looks)
+            unsigned spins = 0;
+            while (done_[(size_t)i].v.load(std::memory_order_acquire) != g) {
+                if (++spins < 4096u) __builtin_ia32_pause();
+                else std::this_thread::yield();
+            }
+        }
         job_ = nullptr;
     }
 
@@ -3042,7 +3049,6 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
         if (status[(size_t)i] != PSA_OK) errors[(size_t)i] = psa_last_error();     // (thread-local in the launcher thread)
     };
     g->workers->run(device_job);
-    const auto t_done = std::chrono::steady_clock::now();
     {
         auto last_issue = t_enter;
         for (const auto& t : issued) last_issue = std::max(last_issue, t);
@@ -3071,7 +3077,6 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
         g->h_recv[i].shard = i;
     }
     g->last_total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count();
-    (void)t_done;
     PSA_TRY(st);
     if (shard_records) std::memcpy(shard_records, g->h_recv, sizeof(psa_result) * (size_t)ndev);
     return psa_fold(g->h_recv, ndev, g->is_max, out);

@@ -963,7 +963,7 @@ struct RescoreArgs {
     int fast_min_exp;               // smallest biased exponent of the running sum the walk handles
     int raw;                        // 1 (one-shot searches): s1 / s2 are the caller's raw ASCII (n1 / m bytes), not codes
     int n1;
-    int certify;                    // 1: try the certified segment sum first (cert2_sum), the walk is its fallback
+    int certify;                    // 1: try the certified segment sum first (cert_sum), the walk is its fallback
     double walk_slack;              // rigorous bound of |sequential fp64 prefix sum - order-free prefix sum| over the m chars
     // blockIdx.y = query of a batch launch: its state lies query_stride... further on (all 0 for one search)
     size_t s2_stride;               // bytes between the queries' codes
@@ -1293,7 +1293,7 @@ __device__ __forceinline__ double cert_value(unsigned long long counts, const do
 // which one wave sorted, and rebuilt the sum's mantissa per event):
 //   * inputs whose running sum hovers near zero or near a power of two (low-entropy alphabets: ACGT with the README
 //     weights has 154 true additions behind the first 64 chars) used to exceed the list and were WALKED (64-130 us);
-//     now up to kCert2MaxEv true additions are applied, 64 at a time;
+//     now up to kCertMaxEv true additions are applied, 64 at a time;
 //   * a shorter critical path in the search's tail: classification and the certificate's first level are ONE pass over
 //     a thread's 16 chars, the head chain runs on a spare wave beside level 2, an event is two v_add_f64.
 // Data of one candidate (LDS, behind its class codes; CertLayout):
@@ -1310,44 +1310,44 @@ __device__ __forceinline__ double cert_value(unsigned long long counts, const do
 // (no rounding can occur), a second one is the reference's own addition of the true char: two dependent adds and a
 // check of the exponents per event instead of the first form's mantissa rebuild (87 -> ~30 ns per event).
 // Nothing is assumed: a state or a state + D whose sign/exponent is not the certified one, a binade with a tie or
-// outside the table, more than kCert2MaxEv true additions or kCert2MaxFail unsettled segments send the candidate to
+// outside the table, more than kCertMaxEv true additions or kCertMaxFail unsettled segments send the candidate to
 // walk_sum.  Tested bit for bit against the oracle for every offset (test_rescore_walk_is_bit_exact, the soak).
-constexpr int kCert2MaxFail = 1024;       // unsettled 16-char segments per candidate
-constexpr int kCert2MaxEv = 1024;         // true additions per candidate the summing wave applies (64 at a time)
-constexpr int kCert2Rows = 48;            // binades of the rounded-class-value table
+constexpr int kCertMaxFail = 1024;       // unsettled 16-char segments per candidate
+constexpr int kCertMaxEv = 1024;         // true additions per candidate the summing wave applies (64 at a time)
+constexpr int kCertRows = 48;            // binades of the rounded-class-value table
 
-struct Cert2Table {                       // per search
-    long long rt[kCert2Rows][4];
-    unsigned tie[kCert2Rows];             // != 0: an addend ties in that binade (round-half-even: the walk's business); a byte per class
+struct CertTable {                       // per search
+    long long rt[kCertRows][4];
+    unsigned tie[kCertRows];             // != 0: an addend ties in that binade (round-half-even: the walk's business); a byte per class
     int emin, pad;
 };
-struct Cert2Head {                        // per candidate
+struct CertHead {                        // per candidate
     unsigned long long total;             // class counts of all m chars
     double head_sum;                      // the reference's sum over the first kCertChain chars
     int nfail;
     int pad;
 };
-constexpr int kCert2Summary = 64;           // words of the bitmap's summary (bit w: bitmap word w is not zero): 65,536 chars
-struct Cert2Layout { int seg_before, segbits, bitmap, summary, fail, ev, bytes, nseg, nwords; };
-__host__ __device__ inline Cert2Layout cert2_layout(int m)
+constexpr int kCertSummary = 64;           // words of the bitmap's summary (bit w: bitmap word w is not zero): 65,536 chars
+struct CertLayout { int seg_before, segbits, bitmap, summary, fail, ev, bytes, nseg, nwords; };
+__host__ __device__ inline CertLayout cert_layout(int m)
 {
-    Cert2Layout L;
+    CertLayout L;
     L.nseg = (m + kCertSeg - 1) / kCertSeg;
     L.nwords = (m + 31) / 32;
-    int at = (int)sizeof(Cert2Head);
+    int at = (int)sizeof(CertHead);
     L.seg_before = at;  at += 8 * (L.nseg + 1);
     L.segbits = at;     at += 4 * ((L.nseg + 1) & ~1);       // per segment: bit t = low class bit of char t, bit 16 + t = high
     L.bitmap = at;      at += 4 * ((L.nwords + 1) & ~1);
-    L.summary = at;     at += 4 * kCert2Summary;
-    L.fail = at;        at += 2 * kCert2MaxFail;             // (pass 4 reuses it for the list of non-zero bitmap words)
-    L.ev = at;          at += 2 * kCert2MaxEv;
+    L.summary = at;     at += 4 * kCertSummary;
+    L.fail = at;        at += 2 * kCertMaxFail;             // (pass 4 reuses it for the list of non-zero bitmap words)
+    L.ev = at;          at += 2 * kCertMaxEv;
     L.bytes = (at + 15) & ~15;
     return L;
 }
-static_assert(sizeof(Cert2Head) == 24, "cert2_layout");
+static_assert(sizeof(CertHead) == 24, "cert_layout");
 
-// the table (any kCert2Rows * 4 threads; `idx` = this thread's entry, `value` = that class's pair score)
-__device__ __forceinline__ void cert2_fill_table(Cert2Table* tb, double value, int fast_min_exp, int idx)
+// the table (any kCertRows * 4 threads; `idx` = this thread's entry, `value` = that class's pair score)
+__device__ __forceinline__ void cert_fill_table(CertTable* tb, double value, int fast_min_exp, int idx)
 {
     const int row = idx >> 2, c = idx & 3;
     const int e = fast_min_exp + row;
@@ -1372,7 +1372,7 @@ __device__ __forceinline__ void cert2_fill_table(Cert2Table* tb, double value, i
 }
 
 // class counts (16 bits per class) of the first `r` chars of a segment from its class bits
-__device__ __forceinline__ unsigned long long cert2_counts_of_bits(unsigned bits, int r)
+__device__ __forceinline__ unsigned long long cert_counts_of_bits(unsigned bits, int r)
 {
     const unsigned pm = (1u << r) - 1u;                      // r <= 16
     const unsigned b0 = bits & pm, b1 = (bits >> 16) & pm;
@@ -1386,7 +1386,7 @@ __device__ __forceinline__ unsigned long long cert2_counts_of_bits(unsigned bits
 // 2 adds the waves in front.  The code is kept SMALL (the four dwords of a segment in a rolled loop): the tail runs once
 // per search on a workgroup whose instruction cache holds the count loop — every byte of it is a cold fetch.
 template <int NT, bool RAW>
-__device__ __forceinline__ unsigned long long cert2_classify(const unsigned char* __restrict__ s1, const unsigned char* __restrict__ s2,
+__device__ __forceinline__ unsigned long long cert_classify(const unsigned char* __restrict__ s1, const unsigned char* __restrict__ s2,
                                                              const unsigned char* s_clsrank, unsigned char* s_codes, int m,
                                                              unsigned long long* seg_before, unsigned* segbits, int tid,
                                                              unsigned long long& key, int limit1, int limit2)
@@ -1458,7 +1458,7 @@ __device__ __forceinline__ unsigned long long cert2_classify(const unsigned char
                 const unsigned bits = b0 | (b1 << 16);
                 segbits[seg] = bits;
                 if (per > 1) seg_before[seg] = mine;         // (relative to the thread's first segment: see below)
-                mine += cert2_counts_of_bits(bits, valid);
+                mine += cert_counts_of_bits(bits, valid);
             }
         } else if (q >= per && seg < nseg_pad) {
             *reinterpret_cast<uint4*>(s_codes + k0) = make_uint4(0x04040404u, 0x04040404u, 0x04040404u, 0x04040404u);
@@ -1482,15 +1482,15 @@ __device__ __forceinline__ unsigned long long cert2_classify(const unsigned char
 }
 
 // ---- pass 2 (every thread, behind the barrier that follows the block scan's wave totals) ----------------------------
-// `before` = class counts of the WAVES in front of this thread's (their totals: lane 63 of cert2_classify's result).
+// `before` = class counts of the WAVES in front of this thread's (their totals: lane 63 of cert_classify's result).
 // Level 1: all prefix sums of a segment lie within A = sum |p_i| of the sum in front of it; that sum A + slack inside its
 // binade settles the segment.  The others go to fail[].  head->nfail must be zero (and the bitmap clear) by now.
 template <int NT>
-__device__ __forceinline__ void cert2_level1(const unsigned char* s_codes, int m, const double* s_class, double slack,
+__device__ __forceinline__ void cert_level1(const unsigned char* s_codes, int m, const double* s_class, double slack,
                                              int fast_min_exp, unsigned char* cert, unsigned long long before, int tid)
 {
-    const Cert2Layout L = cert2_layout(m);
-    Cert2Head* head = reinterpret_cast<Cert2Head*>(cert);
+    const CertLayout L = cert_layout(m);
+    CertHead* head = reinterpret_cast<CertHead*>(cert);
     unsigned long long* seg_before = reinterpret_cast<unsigned long long*>(cert + L.seg_before);
     const unsigned* segbits = reinterpret_cast<const unsigned*>(cert + L.segbits);
     unsigned short* fail = reinterpret_cast<unsigned short*>(cert + L.fail);
@@ -1506,14 +1506,14 @@ __device__ __forceinline__ void cert2_level1(const unsigned char* s_codes, int m
         seg_before[seg] = b;
         if (k0 + kCertSeg > kCertChain) {
             // the segment's own counts: from its class bits
-            const unsigned long long n = cert2_counts_of_bits(segbits[seg], m - k0 < kCertSeg ? m - k0 : kCertSeg);
+            const unsigned long long n = cert_counts_of_bits(segbits[seg], m - k0 < kCertSeg ? m - k0 : kCertSeg);
             double reach = 0.0;
 #pragma unroll
             for (int cc = 0; cc < 4; ++cc) reach += fabs(s_class[cc]) * (double)(unsigned)((n >> (16 * cc)) & 0xffffull);
             unsigned hi32;
             if (!cert_inside(cert_value(b, s_class), reach * 1.0000001 + slack, amin, amax, hi32)) {
                 const int slot = atomicAdd(&head->nfail, 1);
-                if (slot < kCert2MaxFail) fail[slot] = (unsigned short)seg;
+                if (slot < kCertMaxFail) fail[slot] = (unsigned short)seg;
             }
         }
     }
@@ -1521,18 +1521,18 @@ __device__ __forceinline__ void cert2_level1(const unsigned char* s_codes, int m
 
 // ---- pass 3 (every thread, behind a barrier): level 2, a 16-lane row per unsettled segment, a lane per char ----------
 template <int NT>
-__device__ __forceinline__ void cert2_level2(const unsigned char* s_codes, int m, const double* s_class, double slack,
+__device__ __forceinline__ void cert_level2(const unsigned char* s_codes, int m, const double* s_class, double slack,
                                              int fast_min_exp, unsigned char* cert, int tid)
 {
-    const Cert2Layout L = cert2_layout(m);
-    const Cert2Head* head = reinterpret_cast<const Cert2Head*>(cert);
+    const CertLayout L = cert_layout(m);
+    const CertHead* head = reinterpret_cast<const CertHead*>(cert);
     const unsigned long long* seg_before = reinterpret_cast<const unsigned long long*>(cert + L.seg_before);
     const unsigned short* fail = reinterpret_cast<const unsigned short*>(cert + L.fail);
     unsigned* bitmap = reinterpret_cast<unsigned*>(cert + L.bitmap);
     unsigned* summary = reinterpret_cast<unsigned*>(cert + L.summary);
     const int lane = tid & 63, wave = tid >> 6;
     const int nfail = head->nfail;
-    if (nfail > kCert2MaxFail) return;
+    if (nfail > kCertMaxFail) return;
     const double amin = __longlong_as_double((long long)((unsigned long long)(fast_min_exp < 1 ? 1 : fast_min_exp) << 52));
     const double amax = __longlong_as_double(0x7fd0000000000000ll);
     const int row = lane >> 4, col = lane & 15;
@@ -1567,33 +1567,33 @@ __device__ __forceinline__ void cert2_level2(const unsigned char* s_codes, int m
 }
 
 // class counts of chars [0, x), 0 <= x <= m: the segment's prefix + the chars of its segment in front of x
-__device__ __forceinline__ unsigned long long cert2_counts_before(const unsigned* segbits, const unsigned long long* seg_before,
+__device__ __forceinline__ unsigned long long cert_counts_before(const unsigned* segbits, const unsigned long long* seg_before,
                                                                   int x, int m, unsigned long long total)
 {
     if (x >= m) return total;
     const int seg = x >> 4;
-    return seg_before[seg] + cert2_counts_of_bits(segbits[seg], x & 15);
+    return seg_before[seg] + cert_counts_of_bits(segbits[seg], x & 15);
 }
 
 // ---- the sum: ONE wave (all 64 lanes, same arguments), behind the barrier that follows level 2 ------------------------
 // Returns false when the candidate has to be walked instead.
-__device__ __forceinline__ bool cert2_sum(const unsigned char* s_codes, int m, const double* s_class, unsigned char* cert,
-                                          const Cert2Table* tb, int lane, double& s_out)
+__device__ __forceinline__ bool cert_sum(const unsigned char* s_codes, int m, const double* s_class, unsigned char* cert,
+                                          const CertTable* tb, int lane, double& s_out)
 {
 #ifdef PSA_PHASE_TIMING
 #define PSA_SPHASE(k) do { if (lane == 0) g_phase_ts[1004][k] = wall_clock64(); } while (0)
 #else
 #define PSA_SPHASE(k) do { } while (0)
 #endif
-    const Cert2Layout L = cert2_layout(m);
-    const Cert2Head* head = reinterpret_cast<const Cert2Head*>(cert);
+    const CertLayout L = cert_layout(m);
+    const CertHead* head = reinterpret_cast<const CertHead*>(cert);
     const unsigned long long* seg_before = reinterpret_cast<const unsigned long long*>(cert + L.seg_before);
     const unsigned* segbits = reinterpret_cast<const unsigned*>(cert + L.segbits);
     const unsigned* bitmap = reinterpret_cast<const unsigned*>(cert + L.bitmap);
     const unsigned* summary = reinterpret_cast<const unsigned*>(cert + L.summary);
     unsigned short* nzw = reinterpret_cast<unsigned short*>(cert + L.fail);     // (the fail list is dead behind level 2)
     unsigned short* ev = reinterpret_cast<unsigned short*>(cert + L.ev);
-    if (head->nfail > kCert2MaxFail) return false;
+    if (head->nfail > kCertMaxFail) return false;
     PSA_SPHASE(0);
     // ---- the true additions in ascending order, compacted from the bitmap in two steps: the summary (a lane per 32
     // bitmap words) gives the non-zero words in order, then a lane per non-zero word gives the positions
@@ -1603,7 +1603,7 @@ __device__ __forceinline__ bool cert2_sum(const unsigned char* s_codes, int m, c
         const int mine = __popc(sw);
         const int incl = (int)wave_scan_inclusive((long long)mine);
         nzw_count = __builtin_amdgcn_readlane(incl, 63);
-        if (nzw_count > kCert2MaxFail) return false;
+        if (nzw_count > kCertMaxFail) return false;
         int at = incl - mine;
         unsigned w = sw;
         while (w) {
@@ -1620,7 +1620,7 @@ __device__ __forceinline__ bool cert2_sum(const unsigned char* s_codes, int m, c
         const int incl = (int)wave_scan_inclusive((long long)mine);
         int at = nev + incl - mine;
         nev += __builtin_amdgcn_readlane(incl, 63);
-        if (nev > kCert2MaxEv) return false;
+        if (nev > kCertMaxEv) return false;
         while (w) {
             ev[at++] = (unsigned short)(32 * wi + __ffs((int)w) - 1);
             w &= w - 1u;
@@ -1630,7 +1630,7 @@ __device__ __forceinline__ bool cert2_sum(const unsigned char* s_codes, int m, c
     PSA_SPHASE(1);
     const int head_n = m < kCertChain ? m : kCertChain;
     const unsigned long long total = head->total;
-    const unsigned long long at_head = cert2_counts_before(segbits, seg_before, head_n, m, total);
+    const unsigned long long at_head = cert_counts_before(segbits, seg_before, head_n, m, total);
     double s = head->head_sum;                            // the first chars: a plain chain, summed beside level 2
     PSA_SPHASE(2);
     // ---- events, 64 at a time: a lane prepares event i = the interior run behind true addition i - 1 (or the head) and
@@ -1649,16 +1649,16 @@ __device__ __forceinline__ bool cert2_sum(const unsigned char* s_codes, int m, c
             }
             if (i > 0) {
                 from = (int)ev[i - 1] + 1;
-                ca = cert2_counts_before(segbits, seg_before, from, m, total);
+                ca = cert_counts_before(segbits, seg_before, from, m, total);
             }
             if (at > from) {
-                const unsigned long long cb = cert2_counts_before(segbits, seg_before, at, m, total);
+                const unsigned long long cb = cert_counts_before(segbits, seg_before, at, m, total);
                 const unsigned long long cnt = cb - ca;                    // per class, no borrows: counts only grow
                 // the run's binade: the certified one of the sum in front of it
                 const unsigned key = (unsigned)((unsigned long long)__double_as_longlong(cert_value(ca, s_class)) >> 52);
                 const int e = (int)(key & 0x7ffu);
                 const int row = e - tb->emin;
-                if (row < 0 || row >= kCert2Rows || tb->tie[row] != 0u) bad = true;
+                if (row < 0 || row >= kCertRows || tb->tie[row] != 0u) bad = true;
                 else {
                     unsigned long long delta = 0ull;
 #pragma unroll
@@ -1748,7 +1748,7 @@ __device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const Ca
 //   pass 2  block prefix of the counts, the certificate's first level (a thread per segment)
 //   pass 3  the certificate's second level (a 16-lane row per unsettled segment); the head chain of survivor j on wave
 //           WAVES - 1 - j beside it
-//   pass 4  one wave per survivor: true additions compacted, events prepared and applied (cert2_sum; walk_sum if that
+//   pass 4  one wave per survivor: true additions compacted, events prepared and applied (cert_sum; walk_sum if that
 //           declines)
 // four workgroup barriers per round.  More survivors than kFusedMax, or a Seq2 whose codes do not fit the LDS: status 2,
 // the host launches psa_rescore_kernel on the untouched lists.
@@ -1758,10 +1758,10 @@ constexpr int kFusedRound = 4;            // survivors of one round (their per-t
 // LDS in front of the candidates' class codes (finish_search's carve-up) and how many candidates' regions fit at a time
 constexpr int kFusedFixedBytes = (2 * kRow * kRow + (8 + kMaxRanks) * (int)sizeof(double) +
                                   kFusedWaves * (int)sizeof(WalkScratch) + 2 * kFusedRound * kFusedWaves * 8 +
-                                  kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4 + 16 + (int)sizeof(Cert2Table) + 15) & ~15;
+                                  kFusedMax * (int)sizeof(CandRec) + kFusedMax * 4 + 16 + (int)sizeof(CertTable) + 15) & ~15;
 // LDS of one candidate: its class codes + the walk's over-read, then the certificate's data (Seq2 below 65,536 chars)
 __host__ __device__ inline int fused_codes_bytes(int m) { return (m + 64 * kRescoreEpl + 16 + 15) & ~15; }
-__host__ __device__ inline int fused_region_bytes(int m) { return fused_codes_bytes(m) + (m < 65536 ? cert2_layout(m).bytes : 0); }
+__host__ __device__ inline int fused_region_bytes(int m) { return fused_codes_bytes(m) + (m < 65536 ? cert_layout(m).bytes : 0); }
 __host__ __device__ inline int fused_candidates_at_a_time(int lds_bytes, int m)
 {
     const int g = (lds_bytes - kFusedFixedBytes) / fused_region_bytes(m);
@@ -1777,9 +1777,9 @@ template <int WAVES, bool RAW>
 __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned char* lds, int lds_bytes, int tid)
 {
     static_assert(WAVES == kFusedWaves && kFusedRound <= WAVES && kMaxRanks == 16, "kFusedFixedBytes is this carve-up for 16 waves");
-    static_assert(sizeof(WalkScratch) % 16 == 0 && sizeof(CandRec) == 24 && sizeof(Cert2Table) % 8 == 0, "LDS carve-up below");
+    static_assert(sizeof(WalkScratch) % 16 == 0 && sizeof(CandRec) == 24 && sizeof(CertTable) % 8 == 0, "LDS carve-up below");
     constexpr int T = WAVES * 64;
-    static_assert(T >= 4 * kCert2Rows, "the table is filled by the workgroup's last threads");
+    static_assert(T >= 4 * kCertRows, "the table is filled by the workgroup's last threads");
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char* p = lds;
@@ -1793,13 +1793,13 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     CandRec* s_rec = reinterpret_cast<CandRec*>(p);                           p += kFusedMax * sizeof(CandRec);
     int* s_surv = reinterpret_cast<int*>(p);                                  p += kFusedMax * 4;
     int* s_n = reinterpret_cast<int*>(p);                                     p += 16;   // (= lds + kFusedCounterOffset, zero on entry)
-    Cert2Table* s_tab = reinterpret_cast<Cert2Table*>(p);
+    CertTable* s_tab = reinterpret_cast<CertTable*>(p);
     unsigned char* s_codes = lds + kFusedFixedBytes;
     const int m = r.m;
     const bool certify = r.certify != 0;                                      // (host: only for m < 65,536)
     const int codes_bytes = fused_codes_bytes(m);
     const int region = fused_region_bytes(m);                                 // per candidate: codes, certificate
-    const Cert2Layout L = cert2_layout(m < 65536 ? m : 0);
+    const CertLayout L = cert_layout(m < 65536 ? m : 0);
     const int G = fused_candidates_at_a_time(lds_bytes, m);                   // candidates of a round
 
     PSA_FPHASE(0);
@@ -1833,10 +1833,10 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         for (int k = 0; k < 8; ++k) s_class[k] = r.class_value[k];
     }
     // (the rounded-class-value table, by the workgroup's last threads while the loads above are in flight; pass 4 reads it)
-    if (certify && tid >= T - 4 * kCert2Rows) {
-        const int idx = tid - (T - 4 * kCert2Rows), c = idx & 3;
+    if (certify && tid >= T - 4 * kCertRows) {
+        const int idx = tid - (T - 4 * kCertRows), c = idx & 3;
         const double value = c == 0 ? r.class_value[0] : c == 1 ? r.class_value[1] : c == 2 ? r.class_value[2] : r.class_value[3];
-        cert2_fill_table(s_tab, value, r.fast_min_exp, idx);
+        cert_fill_table(s_tab, value, r.fast_min_exp, idx);
     }
     const int count = __builtin_amdgcn_readlane((int)scalar, 9);
     const int bad_flag = __builtin_amdgcn_readlane((int)scalar, 10);
@@ -1887,15 +1887,15 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
             const int o = s_surv[base + j];
             unsigned long long key = 0ull;
             const unsigned long long incl =
-                cert2_classify<T, RAW>(r.s1 + o, r.s2, s_clsrank, codes, m,
+                cert_classify<T, RAW>(r.s1 + o, r.s2, s_clsrank, codes, m,
                                        certify ? reinterpret_cast<unsigned long long*>(cert + L.seg_before) : nullptr,
                                        reinterpret_cast<unsigned*>(cert + L.segbits), tid, key, r.n1 - o, m);
             if (certify) {
                 // (level 2 sets the bits, behind two barriers) bitmap and summary lie side by side: one clearing loop
                 unsigned* bitmap = reinterpret_cast<unsigned*>(cert + L.bitmap);
-                const int words = (L.summary - L.bitmap) / 4 + kCert2Summary;
+                const int words = (L.summary - L.bitmap) / 4 + kCertSummary;
                 for (int w = tid; w < words; w += T) bitmap[w] = 0u;
-                if (tid == 0) reinterpret_cast<Cert2Head*>(cert)->nfail = 0;
+                if (tid == 0) reinterpret_cast<CertHead*>(cert)->nfail = 0;
             }
 #ifdef PSA_PHASE_TIMING
             if (tid == 0) g_phase_ts[1005][3] = wall_clock64();
@@ -1921,8 +1921,8 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
                 const unsigned long long scan = (unsigned long long)wave_scan_inclusive((long long)tot);
                 const unsigned long long before = (unsigned long long)readlane64((long long)(scan - tot), wave);
                 const unsigned long long all = (unsigned long long)readlane64((long long)scan, WAVES - 1);
-                if (tid == 0) reinterpret_cast<Cert2Head*>(cert)->total = all;
-                cert2_level1<T>(codes, m, s_class, r.walk_slack, r.fast_min_exp, cert, before, tid);
+                if (tid == 0) reinterpret_cast<CertHead*>(cert)->total = all;
+                cert_level1<T>(codes, m, s_class, r.walk_slack, r.fast_min_exp, cert, before, tid);
             }
             __syncthreads();
             PSA_FPHASE(3);
@@ -1930,12 +1930,12 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
             for (int j = 0; j < cnt; ++j) {
                 unsigned char* codes = s_codes + (size_t)j * region;
                 unsigned char* cert = codes + codes_bytes;
-                cert2_level2<T>(codes, m, s_class, r.walk_slack, r.fast_min_exp, cert, tid);
+                cert_level2<T>(codes, m, s_class, r.walk_slack, r.fast_min_exp, cert, tid);
                 if (wave == WAVES - 1 - j) {
                     // the first chars: a plain chain (cpu_funcs.c:278), lanes past the end hold +0.0
                     const int head_n = m < kCertChain ? m : kCertChain;
                     const double hs = chain64(0.0, lane < head_n ? s_class[codes[lane] & 7u] : 0.0);
-                    if (lane == 0) reinterpret_cast<Cert2Head*>(cert)->head_sum = hs;
+                    if (lane == 0) reinterpret_cast<CertHead*>(cert)->head_sum = hs;
                 }
             }
             __syncthreads();
@@ -1954,7 +1954,7 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
             if constexpr (RAW) { sym2 = ascii_code(sym2); sym1 = ascii_code(sym1); }
             WalkStats st = {0, 0, 0};
             double s = 0.0;
-            if (!certify || !cert2_sum(codes, m, s_class, codes + codes_bytes, s_tab, lane, s))
+            if (!certify || !cert_sum(codes, m, s_class, codes + codes_bytes, s_tab, lane, s))
                 s = walk_sum(0.0, codes, 0, m, s_class, &s_walk[wave], r.fast_ok, r.fast_min_exp, lane, st);
             if (lane == 0) {
                 CandRec c;
@@ -2002,7 +2002,7 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     if (tid == 0) {
         g_phase_ts[1003][0] = (unsigned long long)count;
         g_phase_ts[1003][1] = (unsigned long long)nsurv;
-        g_phase_ts[1003][2] = certify ? (unsigned long long)reinterpret_cast<const Cert2Head*>(s_codes + codes_bytes)->nfail : 0ull;
+        g_phase_ts[1003][2] = certify ? (unsigned long long)reinterpret_cast<const CertHead*>(s_codes + codes_bytes)->nfail : 0ull;
     }
 #endif
 }
@@ -2675,11 +2675,11 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     __shared__ double             s_class[8];     // the class values, indexable (a by-value kernel argument indexed
                                                   // at run time would be copied to scratch by every lane)
     __shared__ unsigned long long s_key[kRescoreThreads / 64];
-    // the certificate of a Seq2 that is staged whole (m <= kRescoreChunk): cert2_layout(kRescoreChunk) bytes
-    constexpr int kCertBytes = ((int)sizeof(Cert2Head) + 8 * (kRescoreChunk / kCertSeg + 1) + 4 * (kRescoreChunk / kCertSeg + 2) +
-                                4 * (kRescoreChunk / 32 + 2) + 4 * kCert2Summary + 2 * kCert2MaxFail + 2 * kCert2MaxEv + 15) & ~15;
+    // the certificate of a Seq2 that is staged whole (m <= kRescoreChunk): cert_layout(kRescoreChunk) bytes
+    constexpr int kCertBytes = ((int)sizeof(CertHead) + 8 * (kRescoreChunk / kCertSeg + 1) + 4 * (kRescoreChunk / kCertSeg + 2) +
+                                4 * (kRescoreChunk / 32 + 2) + 4 * kCertSummary + 2 * kCertMaxFail + 2 * kCertMaxEv + 15) & ~15;
     __shared__ __attribute__((aligned(16))) unsigned char s_cert[kCertBytes];
-    __shared__ Cert2Table         s_tab;
+    __shared__ CertTable         s_tab;
     __shared__ unsigned long long s_wsum[kRescoreThreads / 64];
     __shared__ int s_last;
     extern __shared__ unsigned char s_pad[];      // never touched: only makes the workgroup too big to share a
@@ -2724,11 +2724,11 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
 #pragma unroll
         for (int k = 0; k < 8; ++k) s_class[k] = a.class_value[k];
     }
-    static_assert(kRescoreThreads >= 4 * kCert2Rows, "the table is filled by the workgroup's last threads");
-    if (a.certify && tid >= kRescoreThreads - 4 * kCert2Rows) {     // (read behind the barriers of the first candidate's passes)
-        const int idx = tid - (kRescoreThreads - 4 * kCert2Rows), c = idx & 3;
+    static_assert(kRescoreThreads >= 4 * kCertRows, "the table is filled by the workgroup's last threads");
+    if (a.certify && tid >= kRescoreThreads - 4 * kCertRows) {     // (read behind the barriers of the first candidate's passes)
+        const int idx = tid - (kRescoreThreads - 4 * kCertRows), c = idx & 3;
         const double value = c == 0 ? a.class_value[0] : c == 1 ? a.class_value[1] : c == 2 ? a.class_value[2] : a.class_value[3];
-        cert2_fill_table(&s_tab, value, a.fast_min_exp, idx);
+        cert_fill_table(&s_tab, value, a.fast_min_exp, idx);
     }
     __syncthreads();
     const double final_best = key_order(*a.global_best);
@@ -2748,16 +2748,16 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
     if (a.certify && m <= kRescoreChunk) {
         // ---- the whole Seq2 is staged: classification + certificate in the passes of finish_search (one candidate),
         // the certified sum on wave 0, the head chain on the last wave beside level 2
-        static_assert(kRescoreChunk < 65536, "cert2_layout");
-        const Cert2Layout L = cert2_layout(m);
-        Cert2Head* head = reinterpret_cast<Cert2Head*>(s_cert);
+        static_assert(kRescoreChunk < 65536, "cert_layout");
+        const CertLayout L = cert_layout(m);
+        CertHead* head = reinterpret_cast<CertHead*>(s_cert);
         {
             unsigned* bitmap = reinterpret_cast<unsigned*>(s_cert + L.bitmap);
-            const int words = (L.summary - L.bitmap) / 4 + kCert2Summary;
+            const int words = (L.summary - L.bitmap) / 4 + kCertSummary;
             for (int w = tid; w < words; w += kRescoreThreads) bitmap[w] = 0u;
             if (tid == 0) head->nfail = 0;
         }
-        const unsigned long long incl = cert2_classify<kRescoreThreads, false>(
+        const unsigned long long incl = cert_classify<kRescoreThreads, false>(
             s1, a.s2, s_clsrank, s_codes, m, reinterpret_cast<unsigned long long*>(s_cert + L.seg_before),
             reinterpret_cast<unsigned*>(s_cert + L.segbits), tid, key, 0, 0);
         if (lane == 63) s_wsum[tid >> 6] = incl;
@@ -2771,10 +2771,10 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
             const unsigned long long before = (unsigned long long)readlane64((long long)(scan - tot), wave);
             const unsigned long long all = (unsigned long long)readlane64((long long)scan, kWaves - 1);
             if (tid == 0) head->total = all;
-            cert2_level1<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, s_cert, before, tid);
+            cert_level1<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, s_cert, before, tid);
         }
         __syncthreads();
-        cert2_level2<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, s_cert, tid);
+        cert_level2<kRescoreThreads>(s_codes, m, s_class, a.walk_slack, a.fast_min_exp, s_cert, tid);
         if ((tid >> 6) == kRescoreThreads / 64 - 1) {
             const int head_n = m < kCertChain ? m : kCertChain;
             const double hs = chain64(0.0, lane < head_n ? s_class[s_codes[lane] & 7u] : 0.0);
@@ -2782,7 +2782,7 @@ __global__ __launch_bounds__(kRescoreThreads) void psa_rescore_kernel(RescoreArg
         }
         __syncthreads();
         if (tid < 64) {
-            if (!cert2_sum(s_codes, m, s_class, s_cert, &s_tab, lane, s)) {
+            if (!cert_sum(s_codes, m, s_class, s_cert, &s_tab, lane, s)) {
                 st.left += 1000;                        // (phase-timing builds: the walk was needed)
                 s = walk_sum(0.0, s_codes, 0, m, s_class, &s_walk, a.fast_ok, a.fast_min_exp, lane, st);
             }
