@@ -1568,6 +1568,39 @@ def test_long_seq2_multi_chunk_path(psa, psa_debug, oracle):
             assert c.fallback_count() == 0
 
 
+@pytest.mark.parametrize("n,m", [(200_000, 70_000), (150_000, 33_000), (120_000, 16_400)])
+def test_very_long_seq2_tail_paths(psa, n, m):
+    """The search's tail beyond its usual shape: |Seq2| >= 65,536 (no certificate: the survivors are classified and
+    WALKED inside the count kernel), 32,768 < |Seq2| < 65,536 (certificate inside the count kernel with several
+    segments per thread; psa_rescore_kernel walks in chunks), just above 16,384 (two segments for some threads) —
+    single search, one-shot search from raw ASCII and batch against the sequential engine (the independent kernel),
+    both modes, a planted copy among the queries."""
+    import torch
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    s1 = psa.generate_sequence(771, n)
+    qs = [psa.generate_sequence(772, m), s1[4321:4321 + m]]
+    t1 = torch.frombuffer(bytearray(s1), dtype=torch.uint8).cuda()
+    with psa.Context(0) as cf, psa.Context(0) as cs:
+        cf.set_engine(psa.ENGINE_FILTER)
+        cs.set_engine(psa.ENGINE_SEQUENTIAL)
+        for is_max in (True, False):
+            cf.set_weights(W_README, is_max)
+            cs.set_weights(W_README, is_max)
+            cs.set_seq1(s1)
+            want = []
+            for q in qs:
+                cs.set_seq2(q)
+                want.append(key(cs.search()))
+                cf.set_sequences(s1, q)
+                assert key(cf.search()) == want[-1], (n, m, is_max)
+                t2 = torch.frombuffer(bytearray(q), dtype=torch.uint8).cuda()
+                torch.cuda.synchronize()
+                assert key(cf.search_device(t1.data_ptr(), n, t2.data_ptr(), m)) == want[-1], (n, m, is_max, "one-shot")
+            cf.set_seq1(s1)
+            assert [key(r) for r in cf.search_batch(qs)] == want
+        assert cf.fallback_count() == 0
+
+
 def test_drop_in_program_all_records(psa, oracle, reference_records, tmp_path):
     """psa_main --all: every stacked record of the reference's input.txt == the oracle."""
     import shutil
