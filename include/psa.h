@@ -245,8 +245,10 @@ psa_status psa_search_sharded(psa_group* g, int first_offset, int last_offset, p
                               psa_result* shard_records);
 
 /* Host time of the group's last psa_search_sharded / psa_search_batch_sharded, microseconds from the call's entry:
- * issue_us = until the last device's work had been enqueued (every device has a persistent launcher thread, so the
- * devices are served side by side, not one after the other), total_us = until the call returned.  Either may be NULL. */
+ * issue_us = until the last device's search launch had been enqueued (every device has a persistent launcher thread, so
+ * the devices are served side by side, not one after the other; for a batch: until the last device's block — a
+ * blocking psa_search_batch on its thread — had returned and its exchange was enqueued), total_us = until the call
+ * returned.  Either may be NULL. */
 psa_status psa_group_last_timing(const psa_group* g, double* issue_us, double* total_us);
 
 /* A batch of queries over the group (BASELINE.json configs[4] on several GPUs): nq queries of m characters, `stride`
