@@ -1632,12 +1632,12 @@ psa_status ensure_pool(psa_context* c, int nq)
 // process that makes one gpu_run_program call does not pay for two it never uses).
 psa_status ensure_batch_objects(psa_context* c)
 {
-    if (c->aux) return PSA_OK;
-    PSA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-    PSA_HIP(hipStreamCreateWithFlags(&c->twin, hipStreamNonBlocking));
+    // (every object on its own: a creation that failed half-way is taken up where it stopped)
+    if (!c->aux) PSA_HIP(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
+    if (!c->twin) PSA_HIP(hipStreamCreateWithFlags(&c->twin, hipStreamNonBlocking));
     for (auto& s : c->slot) {
-        PSA_HIP(hipEventCreateWithFlags(&s.front_done, hipEventDisableTiming));
-        PSA_HIP(hipEventCreateWithFlags(&s.back_done, hipEventDisableTiming));
+        if (!s.front_done) PSA_HIP(hipEventCreateWithFlags(&s.front_done, hipEventDisableTiming));
+        if (!s.back_done) PSA_HIP(hipEventCreateWithFlags(&s.back_done, hipEventDisableTiming));
     }
     return PSA_OK;
 }
@@ -3115,17 +3115,18 @@ psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, i
     const bool rccl = g->exchange == PSA_EXCHANGE_RCCL;
     const int per = psa_query_block_max(nq, ndev);          // records per device and mode in the exchange (the largest block)
     if (per > g->batch_per) {
+        g->batch_per = 0;
         for (size_t i = 0; i < g->d_bsend.size(); ++i) {
             PSA_HIP(hipSetDevice(g->devices[i]));
             (void)hipFree(g->d_bsend[i]);
             (void)hipFree(g->d_brecv[i]);
+            g->d_bsend[i] = g->d_brecv[i] = nullptr;         // (an error return below leaves nothing to free twice)
         }
         if (g->h_bsend) (void)hipHostFree(g->h_bsend);
         if (g->h_brecv) (void)hipHostFree(g->h_brecv);
         g->h_bsend = g->h_brecv = nullptr;
         g->d_bsend.assign((size_t)ndev, nullptr);
         g->d_brecv.assign((size_t)ndev, nullptr);
-        g->batch_per = 0;
         for (int i = 0; i < ndev; ++i) {
             PSA_HIP(hipSetDevice(g->devices[i]));
             PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_bsend[i]), sizeof(psa_result) * 2 * (size_t)per));

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Same-GPU A/B of library variants on the blocking 1M x 10k search (sequences already set): alternating rounds,
-median of 200 searches each.   python tools/search_only_ab.py amd nosplit ...   (psa_amd/libpsa_<name>.so)
+median of 200 searches each.   python tools/search_only_ab.py amd nosplit amd:HIP_FORCE_DEV_KERNARG=1,X=Y ...
+(psa_amd/libpsa_<name>.so, optionally with environment settings for that child).
 Each variant runs in a child process (one library per process)."""
 import os
 import subprocess
@@ -31,7 +32,9 @@ print(f"{1e6 * lat[len(lat) // 2]:.2f} {1e6 * lat[len(lat) // 10]:.2f} {r.offset
 '''
 root = os.path.dirname(HERE)
 for rep in range(3):
-    for name in sys.argv[1:]:
+    for spec in sys.argv[1:]:
+        name, _, settings = spec.partition(":")
         env = dict(os.environ, PSA_ROOT=root, PSA_AMD_LIB=os.path.join(root, "parallel-sequence-alignment_amd", "psa_amd", f"libpsa_{name}.so"))
+        env.update(kv.split("=", 1) for kv in settings.split(",") if kv)
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
-        print(f"{name:12s} search-only median / p10 us, offset: {out.stdout.strip() or out.stderr[-300:]}", flush=True)
+        print(f"{spec:36s} search-only median / p10 us, offset: {out.stdout.strip() or out.stderr[-300:]}", flush=True)
