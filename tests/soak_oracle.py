@@ -106,5 +106,5 @@ with psa.Context(0) as cf, psa.Context(0) as cs, psa.Context(0) as ca, psa.Group
         if time.time() > t_note:
             print(f"{cases} cases so far, all equal to the oracle", flush=True)
             t_note = time.time() + 60.0
-print(f"soak vs oracle: {cases} cases in {budget:.0f} s, seed {seed}: every engine and entry point equals the oracle; "
-      f"fallbacks {cf.fallback_count()} reselects {cf.reselect_count()} unfused {cf.unfused_count()}")
+    print(f"soak vs oracle: {cases} cases in {budget:.0f} s, seed {seed}: every engine and entry point equals the oracle; "
+          f"filter context: fallbacks {cf.fallback_count()} reselects {cf.reselect_count()} unfused {cf.unfused_count()}")
