@@ -120,7 +120,8 @@ void       psa_destroy(psa_context* ctx);
 
 /* weights[4] in reference order (def.h:12-15), is_max as ProgramData.is_max */
 psa_status psa_set_weights(psa_context* ctx, const double weights[4], int is_max);
-/* Host sequences (copied to the device; ASCII, not necessarily NUL-terminated) */
+/* Host sequences (copied to the device; ASCII, not necessarily NUL-terminated).  1 <= n <= PSA_MAX_SEQ1 (2^30, psa_types.h),
+ * in every call that takes a Seq1: longer -> PSA_ERR_ARG before anything is read (tested at 2^30 x 10,000) */
 psa_status psa_set_seq1(psa_context* ctx, const char* seq1, int n);
 psa_status psa_set_seq2(psa_context* ctx, const char* seq2, int m);
 /* Device-resident sequences (raw ASCII bytes already in HBM, e.g. a torch

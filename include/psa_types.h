@@ -39,6 +39,10 @@ extern "C" {
 #define PSA_SEQ2_MAX_LEN (10000 + 1)
 #endif
 
+/* the longest Seq1 the library takes (all lengths and offsets of the C ABI are int; inside, padded lengths, tile counts
+ * and window ends are 32-bit too — 2^30 leaves them a factor of two).  Longer: PSA_ERR_ARG. */
+#define PSA_MAX_SEQ1 (1 << 30)
+
 /* pair signs and the weight each one selects */
 #define PSA_SIGN_STAR   '*'   /* identical residues            -> +w[0] */
 #define PSA_SIGN_COLON  ':'   /* same conservative group       -> -w[1] */

@@ -373,6 +373,22 @@ constexpr int kLdsLimit = 160 * 1024 - 1024;   // dynamic LDS a workgroup may as
 constexpr int kCandCap = 2048;        // candidates re-scored per search before falling back
 constexpr int kSeq1Slack = 49152;     // code-27 tail behind Seq1: tile + chunk rounding + staged-window over-read
 constexpr int kSeq2Slack = 32768 + 64;
+// The filter engine splits a long Seq2 into char chunks (grid.y).  A chunk workgroup stages kTile / 32 + class_chars + 1
+// slots per plane row of kRowSlots: class_chars <= 383, i.e. 11 rounds of 32 chars per shift class = 11,264 chars per chunk
+// (the waves' counters would hold 15 rounds).  Up to 186 chunks = 2,095,104 chars: the per-offset counts travel as 21-bit
+// fields.  Longer: the sequential engine.
+constexpr int kMaxChunks = 186;
+constexpr int kChunkRoundsMax = std::min(psa::kMaxWaveChars / 2 / psa::kUnroll, (psa::kRowSlots - psa::kTile / 32 - 1) / psa::kUnroll);
+static_assert(kChunkRoundsMax == 11 && (long long)kMaxChunks * kChunkRoundsMax * psa::kClasses * psa::kUnroll < (1 << 21), "21-bit counts");
+// room behind a Seq2 of m symbols: the class-order buffer holds nchunks * 1024 * ceil(rounds / nchunks) <= 1024 * (rounds +
+// nchunks) symbols (rounds = m in units of 1024, rounded up) + one round of look-ahead, whatever chunk count
+// (<= min(kMaxChunks, rounds)) the planner picks.  Up to 31 rounds (31,744 chars) this is the fixed kSeq2Slack.
+inline int seq2_slack(int m)
+{
+    const int rounds = ((m + psa::kClasses - 1) / psa::kClasses + psa::kUnroll - 1) / psa::kUnroll;
+    const int chunks = std::min(kMaxChunks, rounds);
+    return std::max(kSeq2Slack, (chunks + 1) * psa::kClasses * psa::kUnroll + psa::kUnroll + 64);
+}
 constexpr int kSlots = 2;             // searches in flight inside a batch
 
 struct Scalars {                      // small device-side state of one filter search (zero between searches)
@@ -564,6 +580,7 @@ struct psa_context {
     // device groups: the final kernel of a single search also writes its 32-byte record here (device memory)
     psa_result* record_out = nullptr;
     int         record_shard = -1;
+    size_t      scratch_cap = (size_t)16 << 30;   // bytes of per-chunk counts one search may take (the debug library reads PSA_SCRATCH_CAP)
     // ... and the kernels that finish the queries of a batch write theirs here ([0]: the results / MAX block, [1]: the MIN
     // block of a MIN+MAX batch; device memory, query q at + q).  batch_records_final: the batch ended without the host
     // touching a result (no re-selection, no sequential-engine fallback), so the device blocks are what the host holds.
@@ -723,6 +740,7 @@ psa_status wait_done(psa_context* c)
 // Seq1: ASCII -> symbol codes (the class planes are built per workgroup inside the count kernel)
 psa_status seq1_args(psa_context* c, const void* d_raw, int n, psa::PrepareArgs* a)
 {
+    if (n > PSA_MAX_SEQ1) { set_last_error("seq1 is longer than PSA_MAX_SEQ1 (2^30)"); return PSA_ERR_ARG; }
     const int need = (n + kSeq1Slack + 63) & ~63;
     if (need > c->n_cap) {
         PSA_TRY(dev_alloc(&c->d_s1, (size_t)need));
@@ -755,7 +773,7 @@ bool plan_filter(int first, int last, int m, FilterPlan* best, int max_chunks = 
 // the slot's three Seq2 buffers hold m symbols (+ the planners' slack)
 psa_status ensure_seq2_capacity(SearchSlot& s, int m)
 {
-    const int need = (m + kSeq2Slack + 63) & ~63;
+    const int need = (m + seq2_slack(m) + 63) & ~63;
     if (need > s.m_cap) {
         s.m_cap = 0;
         PSA_TRY(dev_alloc(&s.d_s2rows, (size_t)need));
@@ -1083,8 +1101,7 @@ psa_status launch_sequential(psa_context* c, SearchSlot& s, int first, int last,
 
 // ---- filter engine -------------------------------------------------------------
 // Largest chunk count a Seq2 class buffer is sized for (every chunk rounds its classes up to whole rounds)
-constexpr int kMaxChunks = 24;
-static_assert((kMaxChunks + 1) * psa::kClasses * psa::kUnroll + psa::kUnroll <= kSeq2Slack, "class-order buffer");
+static_assert((24 + 1) * psa::kClasses * psa::kUnroll + psa::kUnroll <= kSeq2Slack, "class-order buffer of up to 24 chunks inside the fixed slack");
 
 bool plan_filter(int first, int last, int m, FilterPlan* best, int max_chunks)
 {
@@ -1575,11 +1592,21 @@ psa_status launch_filter_back(psa_context* c, SearchSlot& s, long long pairs, hi
     return PSA_OK;
 }
 
+// A multi-chunk plan keeps every chunk's counts of every offset in memory until the tile's last chunk workgroup adds
+// them up: nchunks x ntiles x 32 KB.  One search (or one ring buffer of a batch) takes at most the context's scratch_cap (16 GB) of it: a
+// blocking psa_search over more offsets than that runs in pieces (search_in_pieces); every other path answers such a
+// search with the sequential engine.
+size_t chunk_scratch_bytes(const FilterPlan& p)
+{
+    return p.nchunks > 1 ? (size_t)p.nchunks * p.ntiles * psa::kTile * sizeof(unsigned long long) : 0;
+}
+
 bool use_filter(const psa_context* c, int first, int last, int m)
 {
     if (c->engine == PSA_ENGINE_SEQUENTIAL) return false;
     FilterPlan p;
     if (!plan_filter(first, last, m, &p)) return false;      // Seq2 beyond what the count kernels chunk
+    if (chunk_scratch_bytes(p) > c->scratch_cap) return false;
     if (c->engine == PSA_ENGINE_FILTER) return true;
     // Measured on MI355X (tools/engine_threshold.py, round 3 kernels: gpurun_out/engine_threshold_r3.txt), microseconds
     // per blocking search: the sequential engine is a serial chain of m additions per lane, the filter engine has the
@@ -1588,6 +1615,13 @@ bool use_filter(const psa_context* c, int first, int last, int m)
     const double t_sequential = 16.0 + 0.034 * m + pairs / 8.5e6;
     const double t_filter = 36.0 + 0.002 * m + pairs / 2.6e8;
     return t_filter < t_sequential;
+}
+
+// (seq1_args refuses it too; the host variants ask before they stage a gigabyte)
+psa_status check_seq1_length(int n)
+{
+    if (n > PSA_MAX_SEQ1) { set_last_error("seq1 is longer than PSA_MAX_SEQ1 (2^30)"); return PSA_ERR_ARG; }
+    return PSA_OK;
 }
 
 psa_status check_ready(psa_context* c, int m, int first, int last)
@@ -1800,6 +1834,7 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     if (const char* r = std::getenv("PSA_RAW_CONVERTERS")) c->raw_converters = std::max(1, std::min(1024, std::atoi(r)));
     if (const char* r = std::getenv("PSA_RAW_FORCE_TIMEOUT")) c->raw_force_timeout = std::atoi(r) != 0;
     if (const char* r = std::getenv("PSA_SELECT_FROZEN")) c->select_frozen = std::atoi(r) != 0;
+    if (const char* r = std::getenv("PSA_SCRATCH_CAP")) c->scratch_cap = (size_t)std::atoll(r);     // bytes; sends multi-chunk searches through the piece / sequential paths
 #endif
     *out = c;
     return PSA_OK;
@@ -1878,6 +1913,7 @@ psa_status psa_set_seq2_device(psa_context* c, const void* d_seq2, int m)
 psa_status psa_set_seq1(psa_context* c, const char* seq1, int n)
 {
     if (!c || !seq1 || n < 1) { set_last_error("psa_set_seq1: bad arguments"); return PSA_ERR_ARG; }
+    PSA_TRY(check_seq1_length(n));
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     PSA_TRY(stage_pinned_pair(c, seq1, (size_t)n, seq1 + n, 0));
@@ -1909,6 +1945,7 @@ psa_status psa_set_sequences_device(psa_context* c, const void* d_seq1, int n, c
 psa_status psa_set_sequences(psa_context* c, const char* seq1, int n, const char* seq2, int m)
 {
     if (!c || !seq1 || !seq2 || n < 1 || m < 1) { set_last_error("psa_set_sequences: bad arguments"); return PSA_ERR_ARG; }
+    PSA_TRY(check_seq1_length(n));
     DeviceScope device_scope;
     PSA_TRY(ensure_device(c));
     if ((size_t)n >= stream_min()) {
@@ -2127,6 +2164,7 @@ psa_status psa_search_device(psa_context* c, const void* d_seq1, int n, const vo
     if (c->pending) { set_last_error("psa_search_device: a psa_search_async is still in flight"); return PSA_ERR_STATE; }
     const long long total = (long long)n - m + 1;
     if (total < 1) { set_last_error("need 1 <= len(seq2) <= len(seq1)"); return PSA_ERR_ARG; }
+    if (n > PSA_MAX_SEQ1) { set_last_error("seq1 is longer than PSA_MAX_SEQ1 (2^30)"); return PSA_ERR_ARG; }
     if (first < 0 || last > total || first >= last) {
         set_last_error("offset range must satisfy 0 <= first < last <= len(seq1)-len(seq2)+1");
         return PSA_ERR_ARG;
@@ -2182,8 +2220,43 @@ psa_status psa_search_device(psa_context* c, const void* d_seq1, int n, const vo
     return two_launches();
 }
 
+// A long Seq2 (several char chunks) over so many offsets that the chunks' counts would not fit the context's scratch_cap: the range
+// is searched piece by piece (each a complete filter search) and the pieces' winners are folded in the is_swapable order
+// (psa_fold: ties go to the lower offset, i.e. the earlier piece).  0 = no pieces needed.
+static int piece_offsets(const psa_context* c, int first, int last)
+{
+    if (c->engine == PSA_ENGINE_SEQUENTIAL) return 0;
+    const int m = c->slot[0].m;
+    FilterPlan p;
+    if (m < 1 || !plan_filter(first, last, m, &p) || chunk_scratch_bytes(p) <= c->scratch_cap) return 0;
+    long long piece = (long long)last - first;
+    while (piece > psa::kTileStride) {
+        piece = ((piece / 2 + psa::kTileStride - 1) / psa::kTileStride) * psa::kTileStride;
+        if (plan_filter(first, first + (int)piece, m, &p) && chunk_scratch_bytes(p) <= c->scratch_cap) return (int)piece;
+    }
+    return 0;                                      // (one tile's chunks beyond the cap: cannot happen; the sequential engine)
+}
+
 psa_status psa_search(psa_context* c, int first, int last, psa_result* out)
 {
+    if (c && out && !c->pending && c->have_weights && c->n >= 0 && check_ready(c, c->slot[0].m, first, last) == PSA_OK) {
+        const int piece = piece_offsets(c, first, last);
+        if (piece > 0) {
+            psa_result best;
+            bool have = false;
+            for (long long lo = first; lo < last; lo += piece) {
+                const int hi = (int)std::min<long long>(lo + piece, last);
+                psa_result r[2];
+                PSA_TRY(psa_search_async(c, (int)lo, hi));
+                PSA_TRY(psa_search_wait(c, &r[1]));
+                if (have) { r[0] = best; PSA_TRY(psa_fold(r, 2, c->tables.is_max, &best)); }
+                else best = r[1];
+                have = true;
+            }
+            *out = best;
+            return PSA_OK;
+        }
+    }
     PSA_TRY(psa_search_async(c, first, last));
     return psa_search_wait(c, out);
 }
@@ -2225,7 +2298,7 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
     c->timing_valid = false;
     if (c->profiling) PSA_HIP(hipEventRecord(c->ev[0], c->stream));
     // all queries encoded by one launch: [nq][ostride] codes as u32 rows and as bytes
-    const int ostride = (m + kSeq2Slack + 63) & ~63;
+    const int ostride = (m + seq2_slack(m) + 63) & ~63;
     if ((size_t)nq * ostride > c->batch_cap) {
         c->batch_cap = 0;
         PSA_TRY(dev_alloc(&c->d_batch_rows, (size_t)nq * ostride));
@@ -2929,6 +3002,7 @@ psa_status psa_group_set_weights(psa_group* g, const double weights[4], int is_m
 static psa_status group_set_seq(psa_group* g, const char* seq, int len, bool first_seq)
 {
     if (!g || !seq || len < 1) { set_last_error("psa_group_set_seq: bad arguments"); return PSA_ERR_ARG; }
+    if (first_seq) PSA_TRY(check_seq1_length(len));
     DeviceScope device_scope;
     for (psa_context* c : g->ctx) {
         PSA_TRY(ensure_device(c));
@@ -3234,6 +3308,10 @@ double gpu_run_program_layout(const void* cpu_data, size_t seq1_cap, size_t seq2
     const char* seq2 = base + 40 + seq1_cap;
     // A long Seq1 (no NUL in its first 256 KB) is not measured up front: its end is found while it is copied to the
     // device (stream_pair), the encode launch already under way; n = -1 until then.
+    if (seq1_cap > (size_t)PSA_MAX_SEQ1 + 1) {
+        std::fprintf(stderr, "gpu_run_program: seq1[%zu] is longer than this library takes (PSA_MAX_SEQ1 = 2^30)\n", seq1_cap);
+        std::exit(EXIT_FAILURE);
+    }
     const size_t peek = std::min(seq1_cap, stream_min());
     const void* nul = std::memchr(seq1, 0, peek);
     bool stream = !nul && seq1_cap > peek;

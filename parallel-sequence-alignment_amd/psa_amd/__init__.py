@@ -26,6 +26,7 @@ EXCHANGE_RCCL, EXCHANGE_HOST = 0, 1
 # the reference's own (C++-mangled) name of gpu_run_program (cuda_funcs.h:33), exported next to the C name
 CXX_GPU_RUN_PROGRAM = "_Z15gpu_run_programP5_dataP7_mutantii"
 ENGINE_AUTO, ENGINE_SEQUENTIAL, ENGINE_FILTER = 0, 1, 2
+MAX_SEQ1 = 1 << 30          # PSA_MAX_SEQ1 (include/psa_types.h): longer Seq1 -> PSA_ERR_ARG
 
 # every symbol include/psa.h declares (tests check the library exports all of them)
 EXPORTED_SYMBOLS = (

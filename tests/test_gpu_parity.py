@@ -187,6 +187,15 @@ def test_errors(ctx, psa):
             ctx.search(first, last)
         assert e.value.status == psa.PSA_ERR_ARG
     assert ctx.search(0, 4).offset >= 0
+    # a Seq1 beyond PSA_MAX_SEQ1 (2^30) is refused before anything is read or allocated (the pointers are never followed)
+    import torch
+    d = torch.zeros(64, dtype=torch.uint8, device="cuda")
+    for call in (lambda: psa.lib.psa_set_seq1_device(ctx._h, d.data_ptr(), psa.MAX_SEQ1 + 1),
+                 lambda: psa.lib.psa_set_sequences_device(ctx._h, d.data_ptr(), psa.MAX_SEQ1 + 1, d.data_ptr(), 8),
+                 lambda: psa.lib.psa_search_device(ctx._h, d.data_ptr(), psa.MAX_SEQ1 + 1, d.data_ptr(), 8, 0, 1, C.byref(psa.Result())),
+                 lambda: psa.lib.psa_set_seq1(ctx._h, b"A", psa.MAX_SEQ1 + 1)):
+        assert call() == psa.PSA_ERR_ARG and b"PSA_MAX_SEQ1" in psa.lib.psa_last_error()
+    assert ctx.search(0, 4).offset >= 0
 
 
 def test_legacy_gpu_run_program(psa, oracle, reference_records):
@@ -274,6 +283,42 @@ def test_full_size_properties(ctx, oracle, psa):
     for o in rng.integers(0, total, 40):
         s, _, _ = oracle.score_offset(s1, s2, W_README, False, int(o))
         assert s > res.score or (s == res.score and o >= res.offset)
+
+
+def test_seq1_at_the_length_limit(psa, oracle):
+    """|Seq1| = PSA_MAX_SEQ1 = 2^30 (maximum size of the C ABI's Seq1; 264,208 tiles): a planted copy of Seq2 near the end
+    is found by the filter engine over the whole range (1.07 x 10^13 pairs, one launch), the sequential engine agrees on
+    the ranges around the winner and at both ends, both modes, and the winner re-derives on the oracle at its offset."""
+    n, m = psa.MAX_SEQ1, 10_000
+    rng = np.random.default_rng(30)
+    s1 = rng.integers(65, 91, size=n, dtype=np.uint8)
+    s2 = rng.integers(65, 91, size=m, dtype=np.uint8)
+    total = n - m + 1
+    plant = total - 1_234_567
+    s1[plant:plant + m] = s2
+    s1b, s2b = s1.tobytes(), s2.tobytes()
+    del s1
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    with psa.Context(0) as cf, psa.Context(0) as cs:
+        cf.set_engine(psa.ENGINE_FILTER)
+        cs.set_engine(psa.ENGINE_SEQUENTIAL)
+        for c in (cf, cs):
+            c.set_seq1(s1b)
+            c.set_seq2(s2b)
+        for is_max in (True, False):
+            for c in (cf, cs):
+                c.set_weights(W_README, is_max)
+            whole = cf.search()
+            if is_max:
+                assert whole.offset == plant
+            lo, hi = max(0, whole.offset - 500_000), min(total, whole.offset + 500_000)
+            assert key(cs.search(lo, hi)) == key(whole)
+            assert key(cf.search(total - 1_500_000, total)) == key(cs.search(total - 1_500_000, total))
+            assert key(cf.search(0, 1_000_000)) == key(cs.search(0, 1_000_000))
+            window = s1b[whole.offset:whole.offset + m]
+            want_score, want_ci, want_ch = oracle.score_offset(window, s2b, W_README, is_max, 0)
+            assert (whole.score, whole.char_offset, chr(whole.ch)) == (want_score, want_ci, want_ch)
+        assert cf.fallback_count() == 0
 
 
 def test_beyond_one_wave_of_workgroups(psa, oracle):
@@ -1599,6 +1644,81 @@ def test_very_long_seq2_tail_paths(psa, n, m):
             cf.set_seq1(s1)
             assert [key(r) for r in cf.search_batch(qs)] == want
         assert cf.fallback_count() == 0
+
+
+@pytest.mark.parametrize("n,m", [(1_000_000, 400_000), (1_300_000, 1_000_000), (2_300_000, 2_095_104), (2_300_000, 2_095_105)])
+def test_seq2_of_many_chunks(psa, n, m):
+    """A Seq2 far beyond one workgroup's LDS: the filter engine splits it into up to 186 char chunks of 11,264 chars (36,
+    89 and 186 here; the per-offset counts travel as 21-bit fields, so 2,095,104 chars are the last it takes) and stays 20x
+    faster than the sequential engine, whose answers it must equal in both modes; one char more and the AUTO engine IS the
+    sequential one.  A near-copy of Seq2 is planted so that the winner is not an accident of noise."""
+    rng = np.random.default_rng(m % 1000)
+    s1 = rng.integers(65, 91, size=n, dtype=np.uint8)
+    total = n - m + 1
+    at = total // 3
+    s2 = s1[at:at + m].copy()
+    s2[::7] = rng.integers(65, 91, size=len(s2[::7]), dtype=np.uint8)
+    s1b, s2b = s1.tobytes(), s2.tobytes()
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    import time
+    with psa.Context(0) as ca, psa.Context(0) as cs:
+        cs.set_engine(psa.ENGINE_SEQUENTIAL)
+        for is_max in (True, False):
+            took = []
+            for c in (ca, cs):
+                c.set_weights(W_README, is_max)
+                c.set_sequences(s1b, s2b)
+                c.search(0, 1)
+                t0 = time.perf_counter()
+                r = c.search()
+                took.append(time.perf_counter() - t0)
+                if c is ca:
+                    got = key(r)
+            assert got == key(r), (n, m, is_max)
+            if is_max:
+                assert r.offset == at
+            if m <= 2_095_104:
+                assert took[0] * 3 < took[1], (n, m, took)         # the filter engine answered (measured: 20x)
+        assert ca.fallback_count() == 0
+
+
+def test_search_in_pieces_when_the_chunk_counts_exceed_their_cap(psa, psa_debug, oracle, monkeypatch):
+    """A multi-chunk search whose per-chunk counts (nchunks x ntiles x 32 KB) would exceed the context's cap (16 GB; here
+    PSA_SCRATCH_CAP of the debug library: 8 MB): the blocking psa_search runs it in pieces and folds their winners in the
+    is_swapable order; the async / batch / one-shot entry points answer with the sequential engine or through psa_search.
+    All equal the product library's unsplit search and the oracle; a tie-heavy input checks the fold's order."""
+    import torch
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    n, m = 700_000, 30_000                     # 3+ chunks, 165 tiles: 16+ MB of chunk counts
+    cases = [(psa.generate_sequence(881, n), psa.generate_sequence(882, m)),
+             (b"ACGT" * (n // 4), b"ACGT" * (m // 4))]                       # every 4th offset ties
+    monkeypatch.setenv("PSA_SCRATCH_CAP", str(8 << 20))
+    with psa_debug.Context(0) as cd, psa.Context(0) as cp:
+        monkeypatch.delenv("PSA_SCRATCH_CAP")
+        for s1, s2 in cases:
+            for is_max in (True, False):
+                for c in (cd, cp):
+                    c.set_weights(W_README, is_max)
+                    c.set_sequences(s1, s2)
+                want = key(cp.search())
+                assert key(cd.search()) == want                                  # in pieces
+                assert key(cd.search(12_345, 655_432)) == key(cp.search(12_345, 655_432))
+                cd.search_async(0, n - m + 1)                                    # not in pieces: the sequential engine
+                assert key(cd.search_wait()) == want
+                t1 = torch.frombuffer(bytearray(s1), dtype=torch.uint8).cuda()
+                t2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
+                torch.cuda.synchronize()
+                assert key(cd.search_device(t1.data_ptr(), n, t2.data_ptr(), m)) == want
+                cd.set_seq1(s1)
+                assert key(cd.search_batch([s2, s2])[1]) == want
+            lo, hi = max(0, want[1] - 2000), min(n - m + 1, want[1] + 2000)      # (MIN's winner; the whole range costs the oracle 40 s)
+            assert want == key_of(oracle.search(s1, s2, W_README, False, lo, hi, threads=8))
+        assert cd.fallback_count() == 0 or cases[1][0][:4] == b"ACGT"           # (the tie-heavy input may overflow its lists)
+
+
+def key_of(want):
+    score, off, ci, ch = want
+    return (score, off, ci, ord(ch) if ch else 0)
 
 
 def test_drop_in_program_all_records(psa, oracle, reference_records, tmp_path):
