@@ -518,7 +518,6 @@ struct psa_context {
     unsigned char* d_rank = nullptr;
     unsigned char* d_sub = nullptr;
     double*        d_delta = nullptr;
-    unsigned*      d_symbol_planes = nullptr;
     unsigned char* d_clsrank = nullptr;   // class | rank << 3 per pair (rescore kernel)
     // the same weights in the opposite mode (MIN+MAX batches); built on first use
     psa::Tables    alt_tables;
@@ -1335,7 +1334,6 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     if (p.nchunks > 1 && inline_select && !s.d_arrivals) { set_last_error("internal: no arrival counters"); return PSA_ERR_STATE; }
     psa::CountArgs a;
     a.s1 = c->d_s1;
-    a.symbol_planes = c->d_symbol_planes;
     a.classes = s.s2cls;
     a.partial = s.d_partial;
     a.base = base;
@@ -1480,7 +1478,6 @@ psa_status launch_count_duo(psa_context* c, const unsigned* s2cls, size_t s2_str
     if (!duo_fits(m, &a.class_chars, &a.lds_slots)) { set_last_error("internal: duo kernel does not fit"); return PSA_ERR_ARG; }
     const int base = first & ~31;
     a.s1 = c->d_s1;
-    a.symbol_planes = c->d_symbol_planes;
     a.classes = s2cls;
     a.s2_stride = s2_stride;
     a.base = base;
@@ -1740,7 +1737,6 @@ psa_status psa_create(int device, void* stream, psa_context** out)
             const size_t o_delta = take(sizeof(double) * psa::kMaxRanks);
             const size_t o_arank = take(psa::kRow * psa::kRow), o_asub = take(psa::kRow * psa::kRow), o_aclsrank = take(psa::kRow * psa::kRow);
             const size_t o_adelta = take(sizeof(double) * psa::kMaxRanks);
-            const size_t o_planes = take(sizeof(unsigned) * 64);
             const size_t o_bad = take(sizeof(int));
             const size_t o_ctl = take(128);
             const size_t o_rawarr = take(64);
@@ -1761,7 +1757,6 @@ psa_status psa_create(int device, void* stream, psa_context** out)
             c->d_delta = reinterpret_cast<double*>(d + o_delta);
             c->d_alt_rank = d + o_arank;  c->d_alt_sub = d + o_asub;  c->d_alt_clsrank = d + o_aclsrank;
             c->d_alt_delta = reinterpret_cast<double*>(d + o_adelta);
-            c->d_symbol_planes = reinterpret_cast<unsigned*>(d + o_planes);
             c->d_bad = reinterpret_cast<int*>(d + o_bad);
             c->d_ctl = reinterpret_cast<unsigned long long*>(d + o_ctl);
             c->d_raw_arrivals = reinterpret_cast<unsigned*>(d + o_rawarr);
@@ -1794,21 +1789,19 @@ psa_status psa_create(int device, void* stream, psa_context** out)
             c->h_bad = reinterpret_cast<int*>(c->h_arena + 256);
             init_trace("psa_create: pinned arena (one hipHostMalloc)");
         }
-        {
-            // class planes of every Seq1 symbol a over the Seq2 symbols b (group tables only):
-            // word a: bit b = class(a, b) in {'*', '.'};  word 32+a: class in {':', '.'}
-            unsigned planes[64];
-            std::memset(planes, 0, sizeof planes);
-            for (int a = 0; a <= psa::kCodeHyphen; ++a)
-                for (int b = 0; b <= psa::kCodeHyphen; ++b) {
-                    const char sign = psa::sign_of(a, b);
-                    if (sign == PSA_SIGN_STAR || sign == PSA_SIGN_DOT) planes[a] |= 1u << b;
-                    if (sign == PSA_SIGN_COLON || sign == PSA_SIGN_DOT) planes[32 + a] |= 1u << b;
+        // The count kernels' plane build has the pair relation compiled in (plane_symbols, from the group lists of
+        // psa_internal.hpp); the score tables come from psa::sign_of at run time: they must describe the same relation.
+        for (int a = 0; a <= psa::kCodeHyphen; ++a)
+            for (int b = 0; b <= psa::kCodeHyphen; ++b) {
+                const char sign = psa::sign_of(a, b);
+                const bool lo = sign == PSA_SIGN_STAR || sign == PSA_SIGN_DOT, hi = sign == PSA_SIGN_COLON || sign == PSA_SIGN_DOT;
+                if (lo != (((psa::plane_symbols(b, false) >> a) & 1u) != 0u) || hi != (((psa::plane_symbols(b, true) >> a) & 1u) != 0u)) {
+                    set_last_error("internal: the kernels' compiled-in pair relation differs from the host tables'");
+                    return PSA_ERR_STATE;
                 }
-            PSA_HIP(hipMemcpyAsync(c->d_symbol_planes, planes, sizeof planes, hipMemcpyHostToDevice, c->stream));
-            PSA_HIP(hipStreamSynchronize(c->stream));       // (`planes` goes out of scope)
-        }
-        init_trace("psa_create: arena fill + symbol planes copied, stream synchronised");
+            }
+        PSA_HIP(hipStreamSynchronize(c->stream));
+        init_trace("psa_create: arena fill enqueued, stream synchronised");
         return PSA_OK;
     }();
     if (st != PSA_OK) { psa_destroy(c); return st; }

@@ -426,22 +426,164 @@ __global__ __launch_bounds__(256) void psa_encode_pair_streamed_kernel(PrepareAr
     report_done(done);
 }
 
-// out[b] bit t = in[t] bit b  (recursive block swap, Hacker's Delight 7-3, mirrored).  A butterfly of stage j exchanges
-// the high j-bit halves of a with the low halves of b inside every 2j-bit block:
-//     a' = (a & ~(m << j)) | ((b & m) << j)        b' = (b & ~m) | ((a >> j) & m)
-// = one shift + one v_bitop3_b32 ("c ? b : a", 0xd8) each: 4 full-rate instructions.  (Written as xor swaps the compiler
-// spent 4.8 per butterfly, 52 of them half-rate v_bfi_b32: the plane build is VALU-bound, 463 instructions per slot.)
-__device__ __forceinline__ void transpose32(unsigned (&a)[32])
+#ifndef PSA_PLANES_INLINE
+#define PSA_PLANES_INLINE __attribute__((noinline))
+#endif
+// ---- class planes of a slot (32 positions of Seq1) without table lookups -----------------------------------------
+// Row b of a slot: bit t of `lo` = class(Seq1[32 slot + t], b) in {'*', '.'}, of `hi` = class in {':', '.'}.  Round 4's
+// first form looked 32 symbols up in a 64-word table and transposed the 32x32 bit matrix, once for lo and once for hi
+// (two threads per slot, ~450 instructions each: the plane build was 3.7 us of VALU work in every workgroup).  Here one
+// thread turns the slot's 32 bytes into BIT PLANES of the symbol code (byte shuffle + three butterfly stages on 8 dwords:
+// an 8x8 bit transpose in four byte lanes at once), forms the 27 masks "position holds symbol a" as products of two
+// minterms, and ORs them per row — which symbols belong to a row is the reference's group relation, a compile-time
+// constant (psa_internal.hpp), so the ORs are straight-line code: ~230 instructions for both planes of a slot.
+constexpr unsigned plane_symbols(int b, bool hi)        // Seq1 symbols a (bit a) whose pair with Seq2 symbol b is in the plane
 {
-    unsigned m = 0x0000ffffu;
+    unsigned m = 0u;
+    if (b > kCodeHyphen) return 0u;                     // the padding symbol's row is empty
+    for (int a = 0; a <= kCodeHyphen; ++a) {
+        const char s = sign_of_codes(a, b);
+        if (hi ? (s == PSA_SIGN_COLON || s == PSA_SIGN_DOT) : (s == PSA_SIGN_STAR || s == PSA_SIGN_DOT)) m |= 1u << a;
+    }
+    return m;
+}
+
+// w[q] = bytes 4q..4q+3 of the slot -> plane[j] bit t = bit j of byte t
+__device__ __forceinline__ void byte_bit_planes(const unsigned (&w)[8], unsigned (&plane)[8])
+{
+    // dword u <- bytes u, u + 8, u + 16, u + 24 (v_perm_b32: selector bytes 0-3 name the second source, 4-7 the first)
+    unsigned v[8];
 #pragma unroll
-    for (int j = 16; j != 0; j >>= 1, m ^= (m << j)) {
+    for (int u = 0; u < 8; ++u) {
+        const int q = u >> 2, r = u & 3;
+        const unsigned sel = (unsigned)r | ((unsigned)(4 + r) << 8) | 0x0c0c0000u;
+        const unsigned x = __builtin_amdgcn_perm(w[q + 2], w[q], sel);          // bytes u, u + 8
+        const unsigned y = __builtin_amdgcn_perm(w[q + 6], w[q + 4], sel);      // bytes u + 16, u + 24
+        v[u] = __builtin_amdgcn_perm(y, x, 0x05040100u);
+    }
+    // 8x8 bit transpose of (dword index, bit inside the byte), all four byte lanes at once
+    unsigned m = 0x0f0f0f0fu;
 #pragma unroll
-        for (int k = 0; k < 32; k = (k + j + 1) & ~j) {
-            const unsigned x = a[k], y = a[k + j];
-            a[k] = __builtin_amdgcn_bitop3_b32(x, y << j, m << j, 0xd8);
-            a[k + j] = __builtin_amdgcn_bitop3_b32(y, x >> j, m, 0xd8);
+    for (int j = 4; j != 0; j >>= 1, m ^= (m << j)) {
+#pragma unroll
+        for (int k = 0; k < 8; k = (k + j + 1) & ~j) {
+            const unsigned x = v[k], y = v[k + j];
+            v[k] = __builtin_amdgcn_bitop3_b32(x, y << j, m << j, 0xd8);
+            v[k + j] = __builtin_amdgcn_bitop3_b32(y, x >> j, m, 0xd8);
         }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) plane[j] = v[j];
+}
+
+// v_bitop3_b32 looks its result up at index 4 S0 + 2 S1 + S2.  out[x] = "(a, b, c) spell x" (a = bit 0 of x)
+template <int... X>
+__device__ __forceinline__ void minterms3(unsigned a, unsigned b, unsigned c, unsigned (&out)[8], std::integer_sequence<int, X...>)
+{
+    ((out[X] = __builtin_amdgcn_bitop3_b32(a, b, c, 1u << (((X & 1) << 2) | (X & 2) | ((X >> 2) & 1)))), ...);
+}
+// out[y] = "(a, b) spell y" and gate == GATE
+template <int GATE, int... Y>
+__device__ __forceinline__ void minterms2(unsigned a, unsigned b, unsigned gate, unsigned (&out)[4], std::integer_sequence<int, Y...>)
+{
+    ((out[Y] = __builtin_amdgcn_bitop3_b32(a, b, gate, 1u << (((Y & 1) << 2) | (Y & 2) | GATE))), ...);
+}
+
+// The 27 masks eq[a]: bit t set where position t of the slot holds symbol a.  RAW: the bytes are the caller's ASCII
+// ('A'..'Z', '-'; *other = positions holding anything else, 0 bytes included), else symbol codes 0..27 (27 = padding: in
+// no mask).
+template <bool RAW>
+__device__ __forceinline__ void symbol_masks(const unsigned (&w)[8], unsigned (&eq)[27], unsigned* other)
+{
+    unsigned p[8];
+    byte_bit_planes(w, p);
+    unsigned low[8];                                    // minterms of bits 0-2
+    minterms3(p[0], p[1], p[2], low, std::make_integer_sequence<int, 8>{});
+    if constexpr (!RAW) {
+        unsigned high[4];                               // minterms of bits 3-4 (bits 5-7 of a code are zero)
+        minterms2<0>(p[3], p[4], 0u, high, std::make_integer_sequence<int, 4>{});
+#pragma unroll
+        for (int a = 0; a <= kCodeHyphen; ++a) eq[a] = low[a & 7] & high[a >> 3];
+    } else {
+        // letters 0x41..0x5a: bits 7-5 = 010, bits 4-0 = 1..26;  '-' = 0x2d: bits 7-5 = 001, bits 4-0 = 01101
+        const unsigned letter = __builtin_amdgcn_bitop3_b32(p[5], p[6], p[7], 1u << 2);       // !b5 & b6 & !b7
+        const unsigned hyphen = __builtin_amdgcn_bitop3_b32(p[5], p[6], p[7], 1u << 4);       //  b5 & !b6 & !b7
+        unsigned high[4];                               // minterms of bits 3-4, and a letter
+        minterms2<1>(p[3], p[4], letter, high, std::make_integer_sequence<int, 4>{});
+#pragma unroll
+        for (int a = 0; a < kCodeHyphen; ++a) eq[a] = low[(a + 1) & 7] & high[(a + 1) >> 3];
+        eq[kCodeHyphen] = low[5] & __builtin_amdgcn_bitop3_b32(p[3], p[4], hyphen, 1u << ((1 << 2) | 1));   // b3 & !b4 & hyphen
+        unsigned any = 0u;
+#pragma unroll
+        for (int a = 0; a <= kCodeHyphen; ++a) any |= eq[a];
+        *other = ~any;
+    }
+}
+
+// rows 0..kMaskRows-1 of one slot into the plane rows in LDS: {lo, hi} at dst[(b * row_slots + slot) * 2]
+template <int B = 0>
+__device__ __forceinline__ void store_plane_rows(const unsigned (&eq)[27], uint2* dst, int row_slots, int slot)
+{
+    if constexpr (B < kMaskRows) {
+        constexpr unsigned lo_set = plane_symbols(B, false), hi_set = plane_symbols(B, true);
+        unsigned lo = 0u, hi = 0u;
+#pragma unroll
+        for (int a = 0; a <= kCodeHyphen; ++a) {
+            if ((lo_set >> a) & 1u) lo |= eq[a];
+            if ((hi_set >> a) & 1u) hi |= eq[a];
+        }
+        dst[B * row_slots + slot] = make_uint2(lo, hi);
+        store_plane_rows<B + 1>(eq, dst, row_slots, slot);
+    }
+}
+
+// The class planes of a tile's window: slots [slot0, slot0 + lds_slots) of Seq1 -> rows in LDS, one thread per slot.
+// RAW: from the caller's ASCII (never read behind its end: positions from n1 on count as byte 0 and are left out of the
+// alphabet check), else from the encoded Seq1.  Not inlined: the count loop's schedule and registers must not depend on
+// this code (a 2 % difference of the whole loop was measured between two forms of the plane build).
+template <int NT, bool RAW>
+__device__ PSA_PLANES_INLINE void build_tile_planes(const unsigned char* __restrict__ s1, const unsigned char* __restrict__ raw1, int n1,
+                                                    int* bad, int slot0, int lds_slots, uint2* rows, int tid)
+{
+    const uint4* src = reinterpret_cast<const uint4*>(s1 + ((size_t)slot0 << 5));
+    const bool raw_aligned = RAW && (reinterpret_cast<size_t>(raw1) & 15) == 0;
+    bool bad_seen = false;
+    for (int slot = tid; slot < lds_slots; slot += NT) {               // (at most kRowSlots slots: one per thread)
+        unsigned w[8];
+        if constexpr (!RAW) {
+            const uint4 c0 = src[2 * slot], c1 = src[2 * slot + 1];
+            w[0] = c0.x; w[1] = c0.y; w[2] = c0.z; w[3] = c0.w; w[4] = c1.x; w[5] = c1.y; w[6] = c1.z; w[7] = c1.w;
+        } else {
+            const int p0 = (slot0 + slot) << 5;
+            if (raw_aligned && p0 + 32 <= n1) {
+                const uint4* rs = reinterpret_cast<const uint4*>(raw1 + p0);
+                const uint4 c0 = rs[0], c1 = rs[1];
+                w[0] = c0.x; w[1] = c0.y; w[2] = c0.z; w[3] = c0.w; w[4] = c1.x; w[5] = c1.y; w[6] = c1.z; w[7] = c1.w;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    unsigned v = 0u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int p = p0 + 4 * q + r;
+                        v |= (p < n1 ? (unsigned)raw1[p] : 0u) << (8 * r);
+                    }
+                    w[q] = v;
+                }
+            }
+        }
+        unsigned eq[27], other = 0u;
+        symbol_masks<RAW>(w, eq, &other);
+        if constexpr (RAW) {
+            const int in_range = n1 - ((slot0 + slot) << 5);                // chars of this slot inside Seq1
+            const unsigned range = in_range >= 32 ? ~0u : in_range > 0 ? (1u << in_range) - 1u : 0u;
+            bad_seen |= (other & range) != 0u;
+        }
+        store_plane_rows(eq, rows, kRowSlots, slot);
+    }
+    if constexpr (RAW) {
+        if (bad_seen) atomicOr(bad, 1);                 // a character of Seq1 outside [A-Z-]
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's symbol stores have been performed
     }
 }
 
@@ -643,7 +785,7 @@ __device__ __forceinline__ void planes_to_counts(unsigned (&a)[16])
     for (int j = 8; j != 0; j >>= 1, m ^= (m << j)) {
 #pragma unroll
         for (int k = 0; k < 16; k = (k + j + 1) & ~j) {
-            const unsigned x = a[k], y = a[k + j];              // (butterflies as in transpose32: shift + select)
+            const unsigned x = a[k], y = a[k + j];              // (butterflies as in byte_bit_planes: shift + select)
             a[k] = __builtin_amdgcn_bitop3_b32(x, y << j, m << j, 0xd8);
             a[k + j] = __builtin_amdgcn_bitop3_b32(y, x >> j, m, 0xd8);
         }
@@ -2010,7 +2152,6 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
 // ---- count kernel --------------------------------------------------------------
 struct CountArgs {
     const unsigned char* s1;        // Seq1 symbol codes, padded with kCodePad (32 per slot)
-    const unsigned*      symbol_planes;  // [64]: class planes of every Seq1 symbol over the Seq2 symbols
     const unsigned*      classes;   // Seq2 symbols as LDS row offsets (code << kRowShift) in class order (class_index)
     unsigned long long*  partial;   // [nchunks][span_pad]: n_lo | n_hi<<21 | n_both<<42; tile t at t*kTile
     int base;         // first offset of tile 0: the range's first offset rounded down to a multiple of 32
@@ -2164,93 +2305,18 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     // rows are 4 KiB apart: a Seq2 symbol, stored as code << 12, is its row's byte offset.  (A packed-row variant
     // with 8 waves and two workgroups per CU was measured slower than this kernel for every shape: removed.)
     static_assert(WAVES == 16, "one shape: 16 waves, one workgroup per CU");
-    constexpr int row_slots = kRowSlots;
     auto row_of = [](unsigned sym) -> unsigned { return sym; };
 
     // Build the class planes of the window [32*slot0, +kTile+32*class_chars) in LDS: row b
     // (Seq2 symbol), slot s holds {lo, hi}: bit t of lo = class(Seq1[32*(slot0+s)+t], b) in
-    // {'*','.'}, of hi = class in {':','.'}.  A thread fetches the 32 symbol columns of its slot
-    // (symbol_planes: bit b = the relation of that Seq1 symbol to b) and transposes the two 32x32
-    // bit matrices in registers — 14 KB of codes read per workgroup instead of 100 KB of planes.
-    // RAW: the table is indexed by the ASCII byte ([2][256]); bit 31 of a lo entry marks a byte outside [A-Z-]
-    __shared__ unsigned s_planes[RAW ? 512 : 64];
+    // {'*','.'}, of hi = class in {':','.'}.  One thread per slot: its 32 symbols (codes from the encoded Seq1, or the
+    // caller's ASCII) -> the 27 "holds symbol a" masks -> the rows (symbol_masks / store_plane_rows above) — 14 KB of
+    // codes read per workgroup instead of 100 KB of planes, no table, ~230 instructions per slot.
     // The tile's count cells lie behind the exchange area of the waves' counter sums (which covers the plane rows); they
     // are written once, by sum_columns, with plain stores.
     unsigned* const cells = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + kCellOffset);
     PSA_PHASE(0);
-    {
-        // the lower half of the workgroup transposes the lo planes, the upper half the hi planes;
-        // a thread's first 32 codes are fetched together with the symbol table (one memory latency)
-        constexpr int kHalf = WAVES * 32;
-        static_assert(kHalf % 64 == 0, "the split must fall on a wave boundary");
-        const int hi_half = tid >= kHalf ? 1 : 0;
-        int slot = tid - kHalf * hi_half;
-        const uint4* src = reinterpret_cast<const uint4*>(a.s1 + ((size_t)slot0 << 5));
-        const bool raw_aligned = RAW && (reinterpret_cast<size_t>(a.raw1) & 15) == 0;
-        // the 32 symbols of a slot: codes from the encoded Seq1, or the caller's ASCII (never read behind its end:
-        // positions from n1 on hold byte 0 and are left out of the alphabet check)
-        auto fetch = [&](int sl, uint4& c0, uint4& c1) {
-            if constexpr (!RAW) {
-                c0 = src[2 * sl];
-                c1 = src[2 * sl + 1];
-            } else {
-                const int p0 = (slot0 + sl) << 5;
-                if (raw_aligned && p0 + 32 <= a.n1) {
-                    const uint4* rs = reinterpret_cast<const uint4*>(a.raw1 + p0);
-                    c0 = rs[0];
-                    c1 = rs[1];
-                } else {
-                    unsigned w[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        unsigned v = 0u;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int p = p0 + 4 * q + r;
-                            v |= (p < a.n1 ? (unsigned)a.raw1[p] : 0u) << (8 * r);
-                        }
-                        w[q] = v;
-                    }
-                    c0 = make_uint4(w[0], w[1], w[2], w[3]);
-                    c1 = make_uint4(w[4], w[5], w[6], w[7]);
-                }
-            }
-        };
-        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-        if (slot < a.lds_slots) fetch(slot, c0, c1);
-        if constexpr (!RAW) {
-            if (tid < 64) s_planes[tid] = a.symbol_planes[tid];
-        } else if (tid < 256) {
-            const unsigned code = ascii_code((unsigned)tid);
-            const bool real = code <= (unsigned)kCodeHyphen;
-            s_planes[tid] = (real ? a.symbol_planes[code] : 0u) | (real ? 0u : 0x80000000u);
-            s_planes[256 + tid] = real ? a.symbol_planes[32 + code] : 0u;
-        }
-        __syncthreads();
-        const unsigned* tab = s_planes + (RAW ? 256 : 32) * hi_half;
-        unsigned* dst = reinterpret_cast<unsigned*>(lds) + hi_half;
-        unsigned seen = 0u;
-        while (slot < a.lds_slots) {
-            const unsigned w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            const int next = slot + kHalf;
-            if (next < a.lds_slots) fetch(next, c0, c1);
-            unsigned v[32];
-            const int in_range = RAW ? a.n1 - ((slot0 + slot) << 5) : 32;        // chars of this slot inside Seq1
-#pragma unroll
-            for (int t = 0; t < 32; ++t) {
-                v[t] = tab[(w[t >> 2] >> (8 * (t & 3))) & 0xffu];
-                if constexpr (RAW) seen |= t < in_range ? v[t] : 0u;
-            }
-            transpose32(v);
-#pragma unroll
-            for (int b = 0; b < kMaskRows; ++b) dst[(b * row_slots + slot) * 2] = v[b];
-            slot = next;
-        }
-        if constexpr (RAW) {
-            if (seen >> 31) atomicOr(a.bad, 1);             // a character of Seq1 outside [A-Z-]
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's symbol stores have been performed
-        }
-    }
+    build_tile_planes<WAVES * 64, RAW>(a.s1, a.raw1, a.n1, a.bad, slot0, a.lds_slots, lds, tid);
     __syncthreads();
     if constexpr (RAW) {
         // everybody waits until all converters have arrived: the symbols are complete (and, written through, in memory)
@@ -2466,7 +2532,6 @@ constexpr int kScalCountOffset = 8;        // cand_count inside them
 
 struct DuoArgs {
     const unsigned char* s1;
-    const unsigned*      symbol_planes;
     const unsigned*      classes;      // class-ordered symbols of the launch's first query; query q at + q * s2_stride
     size_t               s2_stride;    // in elements
     int base;             // first offset of tile 0 (multiple of 32)
@@ -2517,8 +2582,6 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
     extern __shared__ uint2 lds[];                  // [kMaskRows][kRowSlots] planes, then one scratch per group
     __shared__ unsigned s_bar[2];
     __shared__ unsigned long long s_best[2][kDuoGroupWaves + 1];
-    // the symbol table of the plane build lives in the (not yet used) cells of group 0
-    unsigned* const s_planes = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + kMaskRows * kRowSlots * 8);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2529,31 +2592,8 @@ __global__ __launch_bounds__(1024) void psa_count_duo_kernel(DuoArgs a)
     const int slot0 = tile_o0 >> 5;
 
     // ---- planes of the window [tile_o0, +kTile+32*class_chars): as psa_count_kernel<16>
-    {
-        constexpr int kHalf = 512;
-        const int hi_half = tid >= kHalf ? 1 : 0;
-        int slot = tid - kHalf * hi_half;
-        const uint4* src = reinterpret_cast<const uint4*>(a.s1 + ((size_t)slot0 << 5));
-        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-        if (slot < a.lds_slots) { c0 = src[2 * slot]; c1 = src[2 * slot + 1]; }
-        if (tid < 64) s_planes[tid] = a.symbol_planes[tid];
-        if (tid < 2) s_bar[tid] = 0u;
-        __syncthreads();
-        const unsigned* tab = s_planes + 32 * hi_half;
-        unsigned* dst = reinterpret_cast<unsigned*>(lds) + hi_half;
-        while (slot < a.lds_slots) {
-            const unsigned w[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
-            const int next = slot + kHalf;
-            if (next < a.lds_slots) { c0 = src[2 * next]; c1 = src[2 * next + 1]; }
-            unsigned v[32];
-#pragma unroll
-            for (int t = 0; t < 32; ++t) v[t] = tab[(w[t >> 2] >> (8 * (t & 3))) & 0xffu];
-            transpose32(v);
-#pragma unroll
-            for (int b = 0; b < kMaskRows; ++b) dst[(b * kRowSlots + slot) * 2] = v[b];
-            slot = next;
-        }
-    }
+    if (tid < 2) s_bar[tid] = 0u;
+    build_tile_planes<1024, false>(a.s1, nullptr, 0, nullptr, slot0, a.lds_slots, lds, tid);
     __syncthreads();
     {   // both groups' count cells start from zero
         unsigned* z = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(lds) + kMaskRows * kRowSlots * 8);

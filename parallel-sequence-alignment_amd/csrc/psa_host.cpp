@@ -20,13 +20,7 @@ namespace {
 
 thread_local std::string g_last_error;
 
-// Group lists: cpu_funcs.c:19-20 / cuda_funcs.h:21-22 (README.md:26 lists
-// MSGNDILV for the 4th semi-conservative group; the code says SGND — the
-// code is what the reference executes).
-const char* const kConservative[] = {"NDEQ", "NEQK", "STA", "MILV", "QHRK", "NHQK", "FYW", "HY", "MILF"};
-const char* const kSemiConservative[] = {"SAG", "ATV", "CSA", "SGND", "STPA", "STNK",
-                                         "NEQHRK", "NDEQHK", "SNDEQK", "HFY", "FVLIM"};
-
+// (the group lists: psa_internal.hpp)
 struct GroupMasks {
     uint32_t cons[PSA_ALPHABET];
     uint32_t semi[PSA_ALPHABET];

@@ -17,6 +17,39 @@ constexpr int kCodeBad    = 255;
 constexpr int kRow        = 32;   // row stride of every [c2][c1] table
 constexpr int kMaxRanks   = 16;   // distinct substitution deltas incl. rank 0 = "no substitution"
 
+// Group lists: cpu_funcs.c:19-20 / cuda_funcs.h:21-22 (README.md:26 lists MSGNDILV for the 4th semi-conservative group;
+// the code says SGND — the code is what the reference executes).  constexpr: the host's tables (psa_host.cpp) and the
+// count kernels' plane build (psa_filter_kernels.hpp, which turns the relation into straight-line code) read the same lists.
+inline constexpr const char* kConservative[] = {"NDEQ", "NEQK", "STA", "MILV", "QHRK", "NHQK", "FYW", "HY", "MILF"};
+inline constexpr const char* kSemiConservative[] = {"SAG", "ATV", "CSA", "SGND", "STPA", "STNK",
+                                                    "NEQHRK", "NDEQHK", "SNDEQK", "HFY", "FVLIM"};
+constexpr int kNumConservative = (int)(sizeof kConservative / sizeof *kConservative);
+constexpr int kNumSemiConservative = (int)(sizeof kSemiConservative / sizeof *kSemiConservative);
+
+constexpr bool shares_group(const char* const* groups, int count, int c1, int c2)
+{
+    for (int g = 0; g < count; ++g) {
+        bool has1 = false, has2 = false;
+        for (const char* p = groups[g]; *p; ++p) {
+            has1 = has1 || *p - 'A' == c1;
+            has2 = has2 || *p - 'A' == c2;
+        }
+        if (has1 && has2) return true;
+    }
+    return false;
+}
+
+// sign of a pair of codes (0..26): get_hashtable_sign (cuda_funcs.cu:424-439) over get_pair_sign (cuda_funcs.cu:495-502)
+constexpr char sign_of_codes(int c1, int c2)
+{
+    if (c1 == kCodeHyphen && c2 == kCodeHyphen) return PSA_SIGN_STAR;
+    if (c1 == kCodeHyphen || c2 == kCodeHyphen) return PSA_SIGN_SPACE;
+    if (c1 == c2) return PSA_SIGN_STAR;
+    if (shares_group(kConservative, kNumConservative, c1, c2)) return PSA_SIGN_COLON;
+    if (shares_group(kSemiConservative, kNumSemiConservative, c1, c2)) return PSA_SIGN_DOT;
+    return PSA_SIGN_SPACE;
+}
+
 inline int encode_symbol(unsigned char c)
 {
     if (c >= 'A' && c <= 'Z') return c - 'A';
