@@ -663,7 +663,7 @@ def main():
 
         def legacy():
             score[0] = psa.lib.gpu_run_program_layout(C.addressof(data), cap1, cap2, C.byref(mutant), lo1, hi1)
-        legacy_us = median_us(legacy, sync, reps=12)
+        legacy_us = median_us(legacy, sync, reps=40)          # (12 gave 147 us once on a box whose other probes were normal)
         legacy_equal = (mutant.offset, score[0]) == (one.offset, one.score)
 
     # ---- the CPU baseline: behind the latency probes (13 s of all-core OpenMP work in front of them cost every probe
