@@ -1789,13 +1789,13 @@ psa_status psa_create(int device, void* stream, psa_context** out)
             c->h_bad = reinterpret_cast<int*>(c->h_arena + 256);
             init_trace("psa_create: pinned arena (one hipHostMalloc)");
         }
-        // The count kernels' plane build has the pair relation compiled in (plane_symbols, from the group lists of
+        // The count kernels' plane build has the pair relation compiled in (kPlaneSets, from the group lists of
         // psa_internal.hpp); the score tables come from psa::sign_of at run time: they must describe the same relation.
         for (int a = 0; a <= psa::kCodeHyphen; ++a)
             for (int b = 0; b <= psa::kCodeHyphen; ++b) {
                 const char sign = psa::sign_of(a, b);
                 const bool lo = sign == PSA_SIGN_STAR || sign == PSA_SIGN_DOT, hi = sign == PSA_SIGN_COLON || sign == PSA_SIGN_DOT;
-                if (lo != (((psa::plane_symbols(b, false) >> a) & 1u) != 0u) || hi != (((psa::plane_symbols(b, true) >> a) & 1u) != 0u)) {
+                if (lo != (((psa::kPlaneSets.lo[b] >> a) & 1u) != 0u) || hi != (((psa::kPlaneSets.hi[b] >> a) & 1u) != 0u)) {
                     set_last_error("internal: the kernels' compiled-in pair relation differs from the host tables'");
                     return PSA_ERR_STATE;
                 }

@@ -476,6 +476,16 @@ __device__ __forceinline__ void byte_bit_planes(const unsigned (&w)[8], unsigned
     for (int j = 0; j < 8; ++j) plane[j] = v[j];
 }
 
+// the rows' symbol sets, evaluated by the compiler (psa_create compares them with the host tables' relation)
+struct PlaneSets { unsigned lo[kMaskRows], hi[kMaskRows]; };
+constexpr PlaneSets make_plane_sets()
+{
+    PlaneSets p{};
+    for (int b = 0; b < kMaskRows; ++b) { p.lo[b] = plane_symbols(b, false); p.hi[b] = plane_symbols(b, true); }
+    return p;
+}
+inline constexpr PlaneSets kPlaneSets = make_plane_sets();
+
 // v_bitop3_b32 looks its result up at index 4 S0 + 2 S1 + S2.  out[x] = "(a, b, c) spell x" (a = bit 0 of x)
 template <int... X>
 __device__ __forceinline__ void minterms3(unsigned a, unsigned b, unsigned c, unsigned (&out)[8], std::integer_sequence<int, X...>)
@@ -525,7 +535,7 @@ template <int B = 0>
 __device__ __forceinline__ void store_plane_rows(const unsigned (&eq)[27], uint2* dst, int row_slots, int slot)
 {
     if constexpr (B < kMaskRows) {
-        constexpr unsigned lo_set = plane_symbols(B, false), hi_set = plane_symbols(B, true);
+        constexpr unsigned lo_set = kPlaneSets.lo[B], hi_set = kPlaneSets.hi[B];
         unsigned lo = 0u, hi = 0u;
 #pragma unroll
         for (int a = 0; a <= kCodeHyphen; ++a) {
