@@ -1167,7 +1167,6 @@ psa::BoundParams bound_params(const psa::Tables& t, int m)
 {
     psa::BoundParams b;
     for (int i = 0; i < 4; ++i) {
-        b.w[i] = t.weights[i];
         b.class_best[i] = t.class_best_delta[i];
         b.class_worst[i] = t.class_worst_delta[i];
     }
@@ -1181,6 +1180,13 @@ psa::BoundParams bound_params(const psa::Tables& t, int m)
         }
         b.opt_all = d_opt;
         b.pes_all = d_pes;
+        const double sgn = mx ? 1.0 : -1.0;
+        b.c[0] = sgn * (t.weights[0] + t.weights[3]);
+        b.c[1] = sgn * (t.weights[3] - t.weights[1]);
+        b.c[2] = sgn * (t.weights[3] - t.weights[2]);
+        b.c_m = -sgn * t.weights[3] * (double)m;
+        b.up_all = sgn * d_opt + b.slack;
+        b.pes_all_add = sgn * d_pes - b.slack;
     }
     b.m = m;
     b.is_max = t.is_max;

@@ -952,12 +952,15 @@ __device__ __forceinline__ void read_cells(unsigned (&n)[kCounters][PER], const 
 
 // ---- score interval of one offset from its exact counts ------------------------
 struct BoundParams {
-    double w[4];
     double class_best[4];    // most favourable substitution delta inside each class
     double class_worst[4];   // least favourable delta inside each class
     double slack;            // rounding bound of the sequential sum + this formula
     double opt_all, pes_all; // the best / worst delta over all four classes: what offset_bounds finds whenever every
                              // class occurs at least once in an offset (always, for long random sequences)
+    // the order-free score in "bigger is better" form as three multiply-adds of the counts: with n_ = m - n* - n: - n.,
+    //   sgn (w1 n* - w2 n: - w3 n. - w4 n_) = c[0] n* + c[1] n: + c[2] n. + c_m      (host: bound_params)
+    double c[3], c_m;
+    double up_all, pes_all_add;   // sgn opt_all + slack, sgn pes_all - slack: the interval's ends relative to that score
     int m;
     int is_max;
 };
@@ -984,14 +987,15 @@ __device__ __forceinline__ void offset_bounds(const BoundParams& b, int n_lo, in
 {
     const bool mx = b.is_max != 0;
     const int n0 = n_lo - n_both, n1 = n_hi - n_both, n2 = n_both;   // stars, colons, dots
-    const int n3 = b.m - n0 - n1 - n2;
-    const double total = ((b.w[0] * n0 - b.w[1] * n1) - b.w[2] * n2) - b.w[3] * n3;
-    double d_opt, d_pes;
+    // (three fused multiply-adds; the rounding of the pre-added coefficients, <= 6 u m max|w|, is far inside the slack,
+    // which allows (m + 32) u m max|w| twice over: filter_slack)
+    const double total = fma(b.c[0], (double)n0, fma(b.c[1], (double)n1, fma(b.c[2], (double)n2, b.c_m)));
     if constexpr (ALL_PRESENT) {
-        d_opt = b.opt_all;
-        d_pes = b.pes_all;
+        upper = total + b.up_all;
+        pess = total + b.pes_all_add;
     } else {
-        const int n[4] = {n0, n1, n2, n3};
+        const int n[4] = {n0, n1, n2, b.m - n0 - n1 - n2};
+        double d_opt, d_pes;
         d_opt = d_pes = mx ? -INFINITY : INFINITY;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -999,10 +1003,10 @@ __device__ __forceinline__ void offset_bounds(const BoundParams& b, int n_lo, in
                 d_opt = mx ? fmax(d_opt, b.class_best[k]) : fmin(d_opt, b.class_best[k]);
                 d_pes = mx ? fmax(d_pes, b.class_worst[k]) : fmin(d_pes, b.class_worst[k]);
             }
+        const double sgn = mx ? 1.0 : -1.0;
+        upper = (total + sgn * d_opt) + b.slack;
+        pess = (total + sgn * d_pes) - b.slack;
     }
-    const double sgn = mx ? 1.0 : -1.0;
-    upper = sgn * (total + d_opt) + b.slack;
-    pess = sgn * (total + d_pes) - b.slack;
 }
 
 // does every class occur in the offset with these counts?
