@@ -239,11 +239,21 @@ psa_status psa_group_set_seq1(psa_group* g, const char* seq1, int n);   /* every
 psa_status psa_group_set_seq2(psa_group* g, const char* seq2, int m);
 /* Offsets [first_offset,last_offset) over the group.  shard_records (optional, [ndev]) receives the
  * exchanged per-device records (shard = index in the group; offset -1 for an empty shard).  The last kernel of every
- * device's search writes its record into the exchange's send buffer, the all-gather follows on the same stream, the
- * host waits once (device 0's copy of the records).  The group entry points put the calling thread's current
+ * device's search writes its record into the device's own slot of its receive buffer (the all-gather's in-place form),
+ * the all-gather follows on the same stream, device 0 publishes the gathered records in pinned host memory and the
+ * host polls their flag word — one wait, with a deadline (psa_group_set_timeout).  The group entry points put the calling thread's current
  * device back before they return. */
 psa_status psa_search_sharded(psa_group* g, int first_offset, int last_offset, psa_result* out,
                               psa_result* shard_records);
+
+/* No group call hangs on a device that does not answer (the reference: MPI_Abort, cpu_funcs.c:38-44).  Whatever fails
+ * on one device — selecting it, its launch, a copy — is recorded and that device still takes its part in the exchange, so
+ * no other device's collective waits for a rank that gave up; and every wait has a deadline: `seconds` (default 60) for
+ * device 0's wait for the exchanged records and, with the HOST exchange, for every device's own search.  A call that
+ * gives up returns PSA_ERR_DEVICE, psa_last_error() naming the devices that had not answered.  Until the abandoned work
+ * has drained from the devices' streams the group's next calls fail at once with PSA_ERR_DEVICE (they never queue behind a
+ * stalled device); afterwards the group works as before. */
+psa_status psa_group_set_timeout(psa_group* g, double seconds);
 
 /* Host time of the group's last psa_search_sharded / psa_search_batch_sharded, microseconds from the call's entry:
  * issue_us = until the last device's search launch had been enqueued (every device has a persistent launcher thread, so

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "psa_internal.hpp"
+#include "psa_group_workers.hpp"
 #ifdef PSA_EXPERIMENT
 #include "psa_debug.h"
 #endif
@@ -1372,9 +1373,7 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.tail = rescore_args(c, s, (long long)span * s.m, ts);
     a.tail.record_out = c->record_out;
     a.tail.record_shard = c->record_shard;
-#ifndef PSA_NO_BEST_SPLIT          // (A/B builds: the running bound in one word, as until round 3)
     if (fused && s.d_scal == c->slot[0].d_scal) a.tail.best_split = c->slot[0].d_best_split;     // (a slot's own scalars, not a pool entry)
-#endif
     a.raw1 = a.raw2 = nullptr;
     a.classes_w = nullptr;
     a.bad = c->d_bad;
@@ -2118,7 +2117,23 @@ static bool tail_arrived(const psa_context* c, double spin_us)
     }
 }
 
-psa_status psa_search_wait(psa_context* c, psa_result* out)
+// The stream's work has ended, or `deadline_s` seconds have passed (false).  hipStreamQuery between short sleeps: a wait
+// that can be given up, unlike hipStreamSynchronize (device groups: a stalled device must not hang the call).
+static bool stream_idle_within(hipStream_t stream, double deadline_s)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned looks = 0;; ++looks) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e != hipErrorNotReady) return e == hipSuccess;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > deadline_s) return false;
+        if (looks < 64u) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+}
+
+// deadline_s <= 0: wait as long as it takes (hipStreamSynchronize).  Otherwise the search in flight is given that long to
+// end; PSA_ERR_DEVICE when it has not (the context keeps its `pending` mark: the kernel is still on the stream).
+static psa_status search_wait_impl(psa_context* c, psa_result* out, double deadline_s)
 {
     if (!c || !out) { set_last_error("psa_search_wait: NULL argument"); return PSA_ERR_ARG; }
     if (!c->pending) { set_last_error("psa_search_wait: no search in flight"); return PSA_ERR_STATE; }
@@ -2127,8 +2142,15 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
     PSA_TRY(ensure_device(c));                // (a group waits for several devices' searches in turn; the retry
                                               // paths launch kernels)
     if (c->profiling ||
-        !tail_arrived(c, spin_budget_us(c, c->pending_first, c->pending_last, c->slot[0].m, c->pending_filter)))
-        PSA_HIP(hipStreamSynchronize(c->stream));
+        !tail_arrived(c, spin_budget_us(c, c->pending_first, c->pending_last, c->slot[0].m, c->pending_filter))) {
+        if (deadline_s <= 0.0) {
+            PSA_HIP(hipStreamSynchronize(c->stream));
+        } else if (!stream_idle_within(c->stream, deadline_s)) {
+            set_last_error("the search on device " + std::to_string(c->device) + " has not ended within " +
+                           std::to_string(deadline_s) + " s");
+            return PSA_ERR_DEVICE;
+        }
+    }
     PSA_STRACE(5);
     c->pending = false;
     const psa_status st = settle_search(c);
@@ -2148,6 +2170,8 @@ psa_status psa_search_wait(psa_context* c, psa_result* out)
     }
     return PSA_OK;
 }
+
+psa_status psa_search_wait(psa_context* c, psa_result* out) { return search_wait_impl(c, out, 0.0); }
 
 // One-shot search from raw ASCII in device memory: ONE launch, no encode launch in front of it — the count kernel
 // converts Seq1's windows while it builds its planes, every workgroup writes Seq2's class-ordered symbols itself, and
@@ -2743,6 +2767,7 @@ struct RcclApi {
     void* handle = nullptr;
     decltype(&ncclCommInitAll)  comm_init_all = nullptr;
     decltype(&ncclCommDestroy)  comm_destroy = nullptr;
+    decltype(&ncclCommAbort)    comm_abort = nullptr;     // (optional: a group that gave up on a device)
     decltype(&ncclAllGather)    all_gather = nullptr;
     decltype(&ncclGroupStart)   group_start = nullptr;
     decltype(&ncclGroupEnd)     group_end = nullptr;
@@ -2765,6 +2790,7 @@ bool load_rccl(std::string* err)
     api.handle = h;
     api.comm_init_all = reinterpret_cast<decltype(api.comm_init_all)>(dlsym(h, "ncclCommInitAll"));
     api.comm_destroy = reinterpret_cast<decltype(api.comm_destroy)>(dlsym(h, "ncclCommDestroy"));
+    api.comm_abort = reinterpret_cast<decltype(api.comm_abort)>(dlsym(h, "ncclCommAbort"));
     api.all_gather = reinterpret_cast<decltype(api.all_gather)>(dlsym(h, "ncclAllGather"));
     api.group_start = reinterpret_cast<decltype(api.group_start)>(dlsym(h, "ncclGroupStart"));
     api.group_end = reinterpret_cast<decltype(api.group_end)>(dlsym(h, "ncclGroupEnd"));
@@ -2789,113 +2815,106 @@ bool load_rccl(std::string* err)
 
 }  // namespace
 
-// ---- per-device launcher threads ------------------------------------------------------------------------------
-// A group call has per-device work on the host (select the device, build the launch arguments, enqueue: ~5 us each);
-// issued from one thread the 8th shard of a 0.1 ms search started ~40 us after the first.  The group owns ONE
-// PERSISTENT THREAD PER DEVICE beyond the first (the caller's thread serves device 0): a call rings a doorbell (a
-// generation counter), every thread runs the call's job for its device, the caller waits for their "done" words.
-// A thread keeps polling the doorbell for kHotUs after its last job (back-to-back calls are picked up within a
-// microsecond), then sleeps on a condition variable (an idle group costs nothing; the first call after a pause pays
-// one wake-up).  Every thread selects its device once, when it starts.
-class GroupWorkers {
-public:
-    explicit GroupWorkers(const std::vector<int>& devices) : n_((int)devices.size()), done_((size_t)n_)
-    {
-        for (auto& d : done_) d.v.store(0u);
-        for (int i = 1; i < n_; ++i) threads_.emplace_back([this, i, dev = devices[(size_t)i]] { loop(i, dev); });
-    }
-    ~GroupWorkers()
-    {
-        stop_.store(true);
-        { std::lock_guard<std::mutex> lock(m_); }
-        cv_.notify_all();
-        for (auto& t : threads_) t.join();
-    }
-    GroupWorkers(const GroupWorkers&) = delete;
-    GroupWorkers& operator=(const GroupWorkers&) = delete;
+// ---- per-device launcher threads: csrc/psa_group_workers.hpp (host-only; ThreadSanitizer-tested on the CPU build) ----
+using psa::GroupWorkers;
 
-    // job(i) for every device i of the group: i = 0 on the calling thread, the others on their own; returns when all have
-    template <typename Job>
-    void run(Job&& job)
-    {
-        std::function<void(int)> fn = std::ref(job);
-        job_ = &fn;
-        const unsigned g = gen_.load() + 1u;
-        gen_.store(g);                                   // (seq_cst, like the sleepers' count: see loop)
-        if (sleepers_.load() > 0) {
-            { std::lock_guard<std::mutex> lock(m_); }
-            cv_.notify_all();
-        }
-        job(0);
-        for (int i = 1; i < n_; ++i) {
-            // (a device's share of a blocking search ends within microseconds of the caller's own; a batch's may take
-            // milliseconds: after a short spin the caller gives its core up between looks)
-            unsigned spins = 0;
-            while (done_[(size_t)i].v.load(std::memory_order_acquire) != g) {
-                if (++spins < 4096u) __builtin_ia32_pause();
-                else std::this_thread::yield();
+// ---- the exchange's last step on device 0, and the knobs of the fault tests ------------------------------------------
+namespace {
+
+// Device 0's copy of the gathered records (device memory, complete: the all-gather precedes this launch on the stream)
+// -> pinned host memory the host is POLLING, then the exchange's number as a system-scope release store.  The host sees
+// the records a stream-completion signal earlier than a D2H copy + hipStreamSynchronize would show them (round 4: +15 us
+// per group call), and the wait can be given up: a stalled device cannot hang the caller.  Why not let RCCL receive
+// straight into the pinned buffer: a record written by a library's kernel carries no "last word" the host could trust
+// (a half-written 32-byte record must never be folded); here the flag is ordered behind every record.
+__global__ void __launch_bounds__(256) psa_group_publish_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, int pieces,
+                                                                unsigned* flag, unsigned seq)
+{
+    for (int k = (int)threadIdx.x; k < pieces; k += (int)blockDim.x) dst[k] = src[k];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The flag word shows `want`, or deadline_s seconds have passed (false).
+bool flag_arrived(const unsigned* flag, unsigned want, double deadline_s)
+{
+    const volatile unsigned* f = flag;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        for (int k = 0; k < 256; ++k) {
+            if (*f == want) {
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return true;
             }
+            __builtin_ia32_pause();
         }
-        job_ = nullptr;
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (waited > deadline_s) return false;
+        if (waited > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));   // (a batch: not worth a core)
     }
+}
 
-private:
-    static constexpr double kHotUs = 500.0;
-    struct alignas(64) Done { std::atomic<unsigned> v; };
-
-    void loop(int i, int device)
-    {
-        (void)hipSetDevice(device);
-        unsigned seen = 0u;
-        auto idle_since = std::chrono::steady_clock::now();
-        for (;;) {
-            unsigned g = seen;
-            for (unsigned spins = 1;; ++spins) {
-                g = gen_.load(std::memory_order_acquire);
-                if (g != seen || stop_.load(std::memory_order_relaxed)) break;
-                __builtin_ia32_pause();
-                if ((spins & 1023u) == 0u &&
-                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - idle_since).count() > kHotUs) {
-                    // to sleep.  The count goes up before the doorbell is looked at again (under the lock), the caller
-                    // rings before it looks at the count: one of the two sees the other (both seq_cst).
-                    std::unique_lock<std::mutex> lock(m_);
-                    sleepers_.fetch_add(1);
-                    cv_.wait(lock, [&] { return gen_.load() != seen || stop_.load(); });
-                    sleepers_.fetch_sub(1);
-                }
-            }
-            if (g == seen) return;                       // stop
-            seen = g;
-            (*job_)(i);
-            done_[(size_t)i].v.store(g, std::memory_order_release);
-            idle_since = std::chrono::steady_clock::now();
-        }
-    }
-
-    int n_;
-    std::vector<Done> done_;
-    std::vector<std::thread> threads_;
-    std::atomic<unsigned> gen_{0u};
-    std::atomic<int> sleepers_{0};
-    std::atomic<bool> stop_{false};
-    std::mutex m_;
-    std::condition_variable cv_;
-    const std::function<void(int)>* job_ = nullptr;
+// Fault injection of the group calls — the debug library only (libpsa_debug.so, -DPSA_EXPERIMENT), read per call:
+//   PSA_GROUP_FAULT=launch:K      device K's job fails before its launch
+//   PSA_GROUP_FAULT=exchange:K    ... after its launch, before its part of the exchange
+//   PSA_GROUP_FAULT=stall:K:MS    a kernel that idles for MS milliseconds (bounded: it watches the wall clock) runs on
+//                                 device K's stream in front of its search: a device that does not answer in time
+struct GroupFault {
+    int kind = 0;          // 1 launch, 2 exchange, 3 stall
+    int device = -1;
+    double stall_ms = 0.0;
+    bool hits(int what, int i) const { return kind == what && device == i; }
 };
+
+#ifdef PSA_EXPERIMENT
+__global__ void psa_debug_stall_kernel(unsigned long long ticks)          // 100 MHz ticks
+{
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+#endif
+
+GroupFault group_fault()
+{
+    GroupFault f;
+#ifdef PSA_EXPERIMENT
+    if (const char* e = std::getenv("PSA_GROUP_FAULT")) {
+        char what[16] = {0};
+        int k = -1;
+        double ms = 0.0;
+        if (std::sscanf(e, "%15[a-z]:%d:%lf", what, &k, &ms) >= 2) {
+            f.kind = !std::strcmp(what, "launch") ? 1 : !std::strcmp(what, "exchange") ? 2 : !std::strcmp(what, "stall") ? 3 : 0;
+            f.device = k;
+            f.stall_ms = ms > 0.0 ? (ms < 5000.0 ? ms : 5000.0) : 200.0;
+        }
+    }
+#endif
+    return f;
+}
+
+}  // namespace
 
 struct psa_group {
     std::vector<int>          devices;
     std::vector<psa_context*> ctx;
     int                       exchange = PSA_EXCHANGE_RCCL;
     std::vector<ncclComm_t>   comm;       // RCCL exchange only
-    std::vector<psa_result*>  d_send;     // per device: its 32-byte record, written by the search's last kernel
-    std::vector<psa_result*>  d_recv;     // per device: all ndev records after the exchange
+    // per device: all ndev records after the exchange, and — INSIDE it, at the device's own rank (the all-gather's
+    // in-place form: no local copy) — the 32-byte record the search's last kernel writes
+    std::vector<psa_result*>  d_recv;
+    std::vector<psa_result*>  d_send;     // = d_recv[i] + i
     psa_result*               h_send = nullptr;   // pinned [ndev]: records of empty shards (written by the host)
-    psa_result*               h_recv = nullptr;   // pinned [ndev]: the exchanged records (device 0's copy)
-    // batches: per device a block of `per` records per mode in, all ndev blocks out
-    std::vector<psa_result*>  d_bsend, d_brecv;
+    // pinned, host-coherent, mapped on device 0: [0] the exchange's flag word (64 bytes), then the exchanged records [ndev],
+    // written by psa_group_publish_kernel (RCCL) or by the launcher threads (HOST) and read by the caller
+    unsigned char*            h_pub = nullptr;
+    unsigned*                 h_flag = nullptr;   unsigned*   hd_flag = nullptr;
+    psa_result*               h_recv = nullptr;   psa_result* hd_recv = nullptr;
+    // batches: per device all ndev blocks of `per` records per mode after the exchange; a device's own block is written
+    // INSIDE it, at the device's rank
+    std::vector<psa_result*>  d_brecv;
     psa_result*               h_bsend = nullptr;  // pinned [ndev][2 * per]
-    psa_result*               h_brecv = nullptr;  // pinned [ndev][2 * per] (device 0's copy of the gathered records)
+    psa_result*               h_brecv = nullptr;  psa_result* hd_brecv = nullptr;   // pinned [ndev][2 * per], mapped on device 0
     int                       batch_per = 0;
     int is_max = 1;
     bool have_weights = false;
@@ -2903,7 +2922,80 @@ struct psa_group {
     std::unique_ptr<GroupWorkers> workers;        // one launcher thread per device beyond the first
     // the last group call: microseconds from its entry until the last device's work had been enqueued, and until it returned
     double last_issue_us = 0.0, last_total_us = 0.0;
+    // ---- no call hangs on a device that does not answer
+    unsigned xseq = 0;                            // number of the last exchange (what its flag word will show)
+    double   timeout_s = 60.0;                    // how long a call waits for the devices (psa_group_set_timeout)
+    // how far every device's job of the running call has come: 0 nothing enqueued, 1 its search, 2 its part of the
+    // exchange, -1 its all-gather could not be enqueued (written by its launcher thread, read by device 0's on a timeout)
+    std::unique_ptr<std::atomic<int>[]> stage;
+    // a call gave up waiting: work of it may still be on the devices' streams.  The next call looks (hipStreamQuery) and
+    // goes ahead once every stream has drained; until then it fails at once instead of queueing behind a stalled device.
+    std::atomic<bool> draining{false};
 };
+
+// Where every device of a timed-out call stands (device 0's thread; the stage words order what it reads of the others)
+static std::string stalled_devices(const psa_group* g, bool single_search)
+{
+    std::string s;
+    bool any = false;
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        const int st = g->stage[i].load(std::memory_order_acquire);
+        const psa_context* c = g->ctx[i];
+        const char* what = nullptr;
+        if (st == 0) what = "had not enqueued its work";
+        else if (st == -1) what = "could not enqueue its all-gather";
+        else if (single_search && c->pending && *static_cast<const volatile int*>(&c->h_tails[0].seq) != c->seq) what = "has not finished its search";
+        if (what) {
+            s += std::string(any ? "; " : "") + "device " + std::to_string(g->devices[i]) + " (shard " + std::to_string(i) + ") " + what;
+            any = true;
+        }
+    }
+    return any ? s : std::string("every device had joined: the all-gather itself has not completed");
+}
+
+// A group whose last call timed out takes the next one only when every stream has drained.
+static psa_status group_ready(psa_group* g)
+{
+    if (!g->draining.load()) return PSA_OK;
+    for (size_t i = 0; i < g->ctx.size(); ++i) {
+        psa_context* c = g->ctx[i];
+        PSA_TRY(ensure_device(c));
+        const hipError_t e = hipStreamQuery(c->stream);
+        if (e == hipErrorNotReady) {
+            set_last_error("device " + std::to_string(g->devices[i]) + " (shard " + std::to_string(i) +
+                           ") is still busy with a group call that timed out");
+            return PSA_ERR_DEVICE;
+        }
+        if (e != hipSuccess) { set_last_error(std::string("hipStreamQuery: ") + hipGetErrorString(e)); return PSA_ERR_DEVICE; }
+    }
+    for (psa_context* c : g->ctx) {
+        c->pending = false;
+        c->record_out = nullptr;
+        c->record_shard = -1;
+        for (auto& sl : c->slot) sl.scal_dirty = true;       // (whatever the abandoned search left in the search scalars)
+    }
+    g->draining.store(false);
+    return PSA_OK;
+}
+
+// Device 0's end of an RCCL exchange: the publish launch behind the all-gather, then the bounded wait for its flag.
+static psa_status publish_and_wait(psa_group* g, const psa_result* d_src, psa_result* hd_dst, size_t bytes, unsigned xseq,
+                                   bool single_search, const char* who)
+{
+    psa_context* c = g->ctx[0];
+    PSA_TRY(ensure_device(c));
+    const int pieces = (int)(bytes / sizeof(uint4));
+    hipLaunchKernelGGL(psa_group_publish_kernel, dim3(1), dim3(pieces <= 64 ? 64 : 256), 0, c->stream,
+                       reinterpret_cast<const uint4*>(d_src), reinterpret_cast<uint4*>(hd_dst), pieces, g->hd_flag, xseq);
+    PSA_HIP(hipGetLastError());
+    if (!flag_arrived(g->h_flag, xseq, g->timeout_s)) {
+        g->draining.store(true);
+        set_last_error(std::string(who) + ": the exchange has not completed within " + std::to_string(g->timeout_s) + " s: " +
+                       stalled_devices(g, single_search));
+        return PSA_ERR_DEVICE;
+    }
+    return PSA_OK;
+}
 
 extern "C" {
 
@@ -2926,6 +3018,11 @@ psa_status psa_group_create_ex(const int* devices, int ndev, int exchange, psa_g
     psa_group* g = new psa_group();
     g->devices.assign(devices, devices + ndev);
     g->exchange = exchange;
+    g->stage.reset(new std::atomic<int>[(size_t)ndev]);
+    for (int i = 0; i < ndev; ++i) g->stage[(size_t)i].store(0);
+#ifdef PSA_EXPERIMENT
+    if (const char* t = std::getenv("PSA_GROUP_TIMEOUT_MS")) g->timeout_s = std::atof(t) / 1e3;
+#endif
     psa_status st = [&]() -> psa_status {
         for (int i = 0; i < ndev; ++i) {
             psa_context* c = nullptr;
@@ -2940,12 +3037,22 @@ psa_status psa_group_create_ex(const int* devices, int ndev, int exchange, psa_g
         g->d_recv.assign((size_t)ndev, nullptr);
         for (int i = 0; i < ndev; ++i) {
             PSA_HIP(hipSetDevice(devices[i]));
-            PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_send[i]), sizeof(psa_result)));
             PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_recv[i]), sizeof(psa_result) * (size_t)ndev));
+            PSA_HIP(hipMemset(g->d_recv[i], 0, sizeof(psa_result) * (size_t)ndev));
+            g->d_send[i] = g->d_recv[i] + i;
         }
+        PSA_HIP(hipSetDevice(devices[0]));
         PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_send), sizeof(psa_result) * (size_t)ndev, hipHostMallocPortable));
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_recv), sizeof(psa_result) * (size_t)ndev, hipHostMallocPortable));
-        g->workers.reset(new GroupWorkers(g->devices));
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_pub), 64 + sizeof(psa_result) * (size_t)ndev,
+                              hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+        std::memset(g->h_pub, 0, 64 + sizeof(psa_result) * (size_t)ndev);
+        unsigned char* hd = nullptr;
+        PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), g->h_pub, 0));
+        g->h_flag = reinterpret_cast<unsigned*>(g->h_pub);
+        g->hd_flag = reinterpret_cast<unsigned*>(hd);
+        g->h_recv = reinterpret_cast<psa_result*>(g->h_pub + 64);
+        g->hd_recv = reinterpret_cast<psa_result*>(hd + 64);
+        g->workers.reset(new GroupWorkers(g->devices, [](int device) { (void)hipSetDevice(device); }));
         return PSA_OK;
     }();
     if (st != PSA_OK) { psa_group_destroy(g); return st; }
@@ -2963,20 +3070,29 @@ void psa_group_destroy(psa_group* g)
     if (!g) return;
     DeviceScope device_scope;
     g->workers.reset();                          // the launcher threads end before anything they use is freed
+    // a group that gave up on a device: its streams get a last, bounded chance to drain; what is still busy then is
+    // aborted (RCCL) and its memory is left to the process's end rather than freed under a running kernel
+    bool busy = false;
+    if (g->draining.load())
+        for (psa_context* c : g->ctx)
+            if (hipSetDevice(c->device) != hipSuccess || !stream_idle_within(c->stream, 1.0)) busy = true;
     for (size_t i = 0; i < g->comm.size(); ++i)
-        if (g->comm[i]) (void)g_rccl.comm_destroy(g->comm[i]);
-    for (size_t i = 0; i < g->d_send.size(); ++i) {
+        if (g->comm[i]) (void)(busy && g_rccl.comm_abort ? g_rccl.comm_abort(g->comm[i]) : g_rccl.comm_destroy(g->comm[i]));
+    if (busy) {
+        // (contexts, buffers and pinned memory of a stalled device stay allocated: freeing them would wait for the device)
+        delete g;
+        return;
+    }
+    for (size_t i = 0; i < g->d_recv.size(); ++i) {
         (void)hipSetDevice(g->devices[i]);
-        (void)hipFree(g->d_send[i]);
         (void)hipFree(g->d_recv[i]);
     }
-    for (size_t i = 0; i < g->d_bsend.size(); ++i) {
+    for (size_t i = 0; i < g->d_brecv.size(); ++i) {
         (void)hipSetDevice(g->devices[i]);
-        (void)hipFree(g->d_bsend[i]);
         (void)hipFree(g->d_brecv[i]);
     }
     if (g->h_send) (void)hipHostFree(g->h_send);
-    if (g->h_recv) (void)hipHostFree(g->h_recv);
+    if (g->h_pub) (void)hipHostFree(g->h_pub);
     if (g->h_bsend) (void)hipHostFree(g->h_bsend);
     if (g->h_brecv) (void)hipHostFree(g->h_brecv);
     for (psa_context* c : g->ctx) psa_destroy(c);
@@ -2985,10 +3101,20 @@ void psa_group_destroy(psa_group* g)
 
 int psa_group_size(const psa_group* g) { return g ? (int)g->ctx.size() : 0; }
 
+// How long a group call waits for the devices before it gives up with PSA_ERR_DEVICE (default 60 s): device 0's wait for
+// the exchanged records, and (HOST exchange) every launcher thread's wait for its own search.
+psa_status psa_group_set_timeout(psa_group* g, double seconds)
+{
+    if (!g || !(seconds > 0.0)) { set_last_error("psa_group_set_timeout: bad arguments"); return PSA_ERR_ARG; }
+    g->timeout_s = seconds;
+    return PSA_OK;
+}
+
 psa_status psa_group_set_weights(psa_group* g, const double weights[4], int is_max)
 {
     if (!g) { set_last_error("group is NULL"); return PSA_ERR_ARG; }
     DeviceScope device_scope;
+    PSA_TRY(group_ready(g));
     for (psa_context* c : g->ctx) PSA_TRY(psa_set_weights(c, weights, is_max));
     g->is_max = is_max ? 1 : 0;
     g->have_weights = true;
@@ -3003,6 +3129,7 @@ static psa_status group_set_seq(psa_group* g, const char* seq, int len, bool fir
     if (!g || !seq || len < 1) { set_last_error("psa_group_set_seq: bad arguments"); return PSA_ERR_ARG; }
     if (first_seq) PSA_TRY(check_seq1_length(len));
     DeviceScope device_scope;
+    PSA_TRY(group_ready(g));
     for (psa_context* c : g->ctx) {
         PSA_TRY(ensure_device(c));
         PSA_TRY(stage_host(c, seq, (size_t)len));
@@ -3026,15 +3153,21 @@ psa_status psa_group_set_seq2(psa_group* g, const char* seq2, int m) { return gr
 // of MPI_Allreduce(MAXLOC|MINLOC) + MPI_Send/Recv of the Mutant, cpu_funcs.c:71-94), then the is_swapable fold (ties:
 // lowest offset = lowest shard, like MPI_MAXLOC's lowest rank).
 // Every device's share of the call runs on that device's launcher thread (GroupWorkers), all at once:
-//   RCCL  the search launch (its last kernel writes the record straight into the exchange's send buffer), the device's
-//         ncclAllGather on the same stream — every thread on its own communicator, the multi-thread form of a one-process
-//         communicator set — and, on device 0, the copy of the gathered records to the host and the one wait.  A record
-//         tagged "look again" (candidate-list overflow, too many survivors) or not carrying this search's tag sends that
-//         device through the single-context retry path afterwards.
+//   RCCL  the search launch (its last kernel writes the record straight into the device's slot of its receive buffer:
+//         the all-gather's in-place form), the device's ncclAllGather on the same stream — every thread on its own
+//         communicator, the multi-thread form of a one-process communicator set — and, on device 0, a one-workgroup
+//         kernel that publishes the gathered records in pinned host memory, its flag word last; the caller polls that
+//         word.  A record tagged "look again" (candidate-list overflow, too many survivors) or not carrying this search's
+//         tag sends that device through the single-context retry path afterwards.
 //   HOST  the search launch and the wait for that device's result tail (pinned host memory, written by the search's
 //         last kernel and polled: psa_search_wait, retry paths included); the records meet in host memory.
-// A device whose launch fails still takes part in the all-gather (with whatever its send buffer holds: the tag check
-// rejects it), so the collective cannot be left waiting for it.
+// NO CALL HANGS (the reference: MPI_Abort, cpu_funcs.c:38-44).  (1) Whatever fails on a device's thread — selecting the
+// device, the launch, the copy of an empty shard's record — is recorded, and the thread still reaches its all-gather (with
+// whatever its send slot holds: the tag check rejects it): no other device's collective is left waiting for a rank that
+// returned early.  (2) Every wait has a deadline (psa_group_set_timeout, 60 s): device 0's wait for the flag word, a HOST
+// thread's wait for its search.  A call that gives up returns PSA_ERR_DEVICE naming the devices that had not answered
+// and marks the group "draining": the next call looks at the streams and fails at once while one of them is still busy
+// (it never queues behind a stalled device), and goes ahead as soon as they have drained.
 psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out, psa_result* shard_records)
 {
     if (!g || !out) { set_last_error("psa_search_sharded: NULL argument"); return PSA_ERR_ARG; }
@@ -3046,8 +3179,11 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
     const int ndev = (int)g->ctx.size();
     PSA_TRY(check_ready(g->ctx[0], g->m, first, last));
     DeviceScope device_scope;
+    PSA_TRY(group_ready(g));
     const int total = last - first;
     const bool rccl = g->exchange == PSA_EXCHANGE_RCCL;
+    const GroupFault fault = group_fault();
+    const unsigned xseq = ++g->xseq;
     std::vector<int> lo((size_t)ndev), hi((size_t)ndev), tag((size_t)ndev);
     std::vector<psa_status> status((size_t)ndev, PSA_OK);
     std::vector<std::string> errors((size_t)ndev);
@@ -3058,10 +3194,13 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
         psa_group* g;
         ~Settle()
         {
+            const bool draining = g->draining.load();         // (a device that does not answer is not waited for here either)
             for (psa_context* c : g->ctx) {
                 if (c->pending) {
-                    (void)hipSetDevice(c->device);
-                    (void)hipStreamSynchronize(c->stream);
+                    if (!draining) {
+                        (void)hipSetDevice(c->device);
+                        (void)hipStreamSynchronize(c->stream);
+                    }
                     c->slot[0].scal_dirty = true;
                 }
                 c->pending = false;
@@ -3076,50 +3215,75 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
         hi[i] += first;
         // what the record must carry in `shard` to count as this search's: the shard and the search's number
         tag[i] = i | (((g->ctx[i]->seq + 1) & 0x3fffff) << 8);
+        g->stage[(size_t)i].store(0);
     }
     auto device_job = [&](int i) {
         psa_context* c = g->ctx[(size_t)i];
         DeviceScope scope;                       // (the caller's thread serves device 0: its current device is put back)
-        status[(size_t)i] = [&]() -> psa_status {
-            psa_status launched = PSA_OK;
-            if (hi[i] > lo[i]) {
-                launched = search_async_impl(c, lo[i], hi[i], rccl ? g->d_send[i] : nullptr, tag[i]);
-            } else {
-                psa_result r;                                    // an empty shard: "nothing found" (cuda_funcs.cu:158-161)
-                r.score = g->is_max ? -INFINITY : INFINITY;
-                r.offset = -1; r.char_offset = -1; r.ch = 0; r.pairs = 0;
-                r.shard = tag[i];
-                c->seq += 1;
-                if (rccl) {
-                    g->h_send[i] = r;
-                    launched = ensure_device(c);
-                    if (launched == PSA_OK &&
-                        hipMemcpyAsync(g->d_send[i], &g->h_send[i], sizeof(psa_result), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
-                        set_last_error("psa_search_sharded: copy of an empty shard's record failed");
-                        launched = PSA_ERR_DEVICE;
-                    }
-                } else {
-                    g->h_recv[i] = r;
-                }
-            }
-            issued[(size_t)i] = std::chrono::steady_clock::now();
+        psa_status st = PSA_OK;
+        std::string err;
+        auto note = [&](psa_status s) {          // the first failure is the one reported; the job goes on to its exchange
+            if (s != PSA_OK && st == PSA_OK) { st = s; err = psa_last_error(); }
+        };
+        // ---- this device's search
+        if (fault.hits(1, i)) {
+            set_last_error("injected fault: device fails before its launch");
+            note(PSA_ERR_DEVICE);
+        } else if (hi[i] > lo[i]) {
+#ifdef PSA_EXPERIMENT
+            if (fault.hits(3, i) && ensure_device(c) == PSA_OK)
+                hipLaunchKernelGGL(psa_debug_stall_kernel, dim3(1), dim3(1), 0, c->stream, (unsigned long long)(fault.stall_ms * 1e5));
+#endif
+            note(search_async_impl(c, lo[i], hi[i], rccl ? g->d_send[i] : nullptr, tag[i]));
+        } else {
+            psa_result r;                                    // an empty shard: "nothing found" (cuda_funcs.cu:158-161)
+            r.score = g->is_max ? -INFINITY : INFINITY;
+            r.offset = -1; r.char_offset = -1; r.ch = 0; r.pairs = 0;
+            r.shard = tag[i];
+            c->seq += 1;
             if (rccl) {
-                // (also after a failed launch: the other devices' all-gathers wait for this one)
-                PSA_TRY(ensure_device(c));
-                PSA_NCCL(g_rccl.all_gather(g->d_send[i], g->d_recv[i], sizeof(psa_result), ncclChar, g->comm[i], c->stream));
-                if (i == 0) {
-                    PSA_HIP(hipMemcpyAsync(g->h_recv, g->d_recv[0], sizeof(psa_result) * (size_t)ndev, hipMemcpyDeviceToHost, c->stream));
-                    PSA_HIP(hipStreamSynchronize(c->stream));       // device 0 holds every record: every search has ended
+                g->h_send[i] = r;
+                note(ensure_device(c));
+                if (st == PSA_OK &&
+                    hipMemcpyAsync(g->d_send[i], &g->h_send[i], sizeof(psa_result), hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                    set_last_error("psa_search_sharded: copy of an empty shard's record failed");
+                    note(PSA_ERR_DEVICE);
                 }
-            } else if (launched == PSA_OK && hi[i] > lo[i]) {
-                psa_result r;
-                PSA_TRY(psa_search_wait(c, &r));                    // this device's tail, retry paths included
-                r.shard = tag[i];
+            } else {
                 g->h_recv[i] = r;
             }
-            return launched;
-        }();
-        if (status[(size_t)i] != PSA_OK) errors[(size_t)i] = psa_last_error();     // (thread-local in the launcher thread)
+        }
+        issued[(size_t)i] = std::chrono::steady_clock::now();
+        g->stage[(size_t)i].store(1, std::memory_order_release);
+        if (fault.hits(2, i)) {
+            set_last_error("injected fault: device fails before its part of the exchange");
+            note(PSA_ERR_DEVICE);
+        }
+        // ---- its part of the exchange: every path above arrives here
+        if (rccl) {
+            const ncclResult_t r = g_rccl.all_gather(g->d_send[i], g->d_recv[i], sizeof(psa_result), ncclChar, g->comm[i], c->stream);
+            if (r != ncclSuccess) {
+                set_last_error(std::string("ncclAllGather: ") + g_rccl.error_string(r));
+                note(PSA_ERR_DEVICE);
+                g->stage[(size_t)i].store(-1, std::memory_order_release);
+            } else {
+                g->stage[(size_t)i].store(2, std::memory_order_release);
+            }
+            if (i == 0) note(publish_and_wait(g, g->d_recv[0], g->hd_recv, sizeof(psa_result) * (size_t)ndev, xseq, true, "psa_search_sharded"));
+        } else if (st == PSA_OK && hi[i] > lo[i]) {
+            psa_result r;
+            const psa_status w = search_wait_impl(c, &r, g->timeout_s);     // this device's tail, retry paths included
+            note(w);
+            if (w == PSA_OK) {
+                r.shard = tag[i];
+                g->h_recv[i] = r;
+            } else if (c->pending) {
+                g->draining.store(true);                                     // (gave up: the search is still on the stream)
+            }
+            g->stage[(size_t)i].store(2, std::memory_order_release);
+        }
+        status[(size_t)i] = st;
+        errors[(size_t)i] = err;
     };
     g->workers->run(device_job);
     {
@@ -3130,7 +3294,7 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
     psa_status st = PSA_OK;
     for (int i = 0; i < ndev && st == PSA_OK; ++i)
         if (status[(size_t)i] != PSA_OK) { set_last_error(errors[(size_t)i]); st = status[(size_t)i]; }
-    for (int i = 0; i < ndev; ++i) {
+    for (int i = 0; i < ndev && !g->draining.load(); ++i) {
         psa_context* c = g->ctx[i];
         if (c->pending && st == PSA_OK && g->h_recv[i].shard != tag[i]) {
             // this device's search asks for the host (or its record is not this search's): the single-context path
@@ -3141,13 +3305,15 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
             }
             if (st == PSA_OK) st = settle_search(c);
             if (st == PSA_OK) g->h_recv[i] = c->h_tails[0].result;
-        } else if (c->pending && c->pending_filter) {
+        } else if (c->pending && c->pending_filter && st == PSA_OK) {
             c->slot[0].scal_dirty = false;               // its last workgroup zeroed the search scalars
         }
-        c->pending = false;
-        c->record_out = nullptr;
-        c->record_shard = -1;
-        g->h_recv[i].shard = i;
+        if (st == PSA_OK) {
+            c->pending = false;
+            c->record_out = nullptr;
+            c->record_shard = -1;
+            g->h_recv[i].shard = i;
+        }
     }
     g->last_total_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_enter).count();
     PSA_TRY(st);
@@ -3168,10 +3334,12 @@ psa_status psa_group_last_timing(const psa_group* g, double* issue_us, double* t
 
 // A batch of queries over the group (BASELINE.json configs[4] on several GPUs): the queries are dealt to the devices
 // in contiguous blocks (psa_query_block: as even as possible); every device's launcher thread runs its block through
-// psa_search_batch / _minmax (the records also land in the device's block of the exchange's send buffer, written by the
-// kernels that finish each query) and enqueues its all-gather on the same stream; device 0's thread copies the gathered
-// blocks to the host and waits — one wait.  psa_batch_unpack puts them in query order.  A block with a query the host
-// had to finish (re-selection, sequential-engine fallback) is copied to the device again before the exchange.
+// psa_search_batch / _minmax (the records also land in the device's block of its receive buffer — the all-gather's
+// in-place form — written by the kernels that finish each query) and enqueues its all-gather on the same stream;
+// device 0's thread publishes the gathered blocks in pinned host memory (psa_group_publish_kernel) and polls the flag —
+// one wait, with the group's deadline.  psa_batch_unpack puts them in query order.  A block with a query the host had to
+// finish (re-selection, sequential-engine fallback) is copied to the device again before the exchange.  As in
+// psa_search_sharded a device's thread reaches its all-gather whatever failed before.
 // results_min == NULL: one mode (the group's).  HOST exchange: the blocks meet in pinned host memory.
 psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, int m, size_t stride,
                                     int first, int last, psa_result* results, psa_result* results_min)
@@ -3183,31 +3351,32 @@ psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, i
     if (!g->have_weights || g->n < 0) { set_last_error("weights and seq1 must be set before a search"); return PSA_ERR_STATE; }
     const auto t_enter = std::chrono::steady_clock::now();
     DeviceScope device_scope;
+    PSA_TRY(group_ready(g));
     const int ndev = (int)g->ctx.size();
     const int nmodes = results_min ? 2 : 1;
     const bool rccl = g->exchange == PSA_EXCHANGE_RCCL;
     const int per = psa_query_block_max(nq, ndev);          // records per device and mode in the exchange (the largest block)
     if (per > g->batch_per) {
         g->batch_per = 0;
-        for (size_t i = 0; i < g->d_bsend.size(); ++i) {
+        for (size_t i = 0; i < g->d_brecv.size(); ++i) {
             PSA_HIP(hipSetDevice(g->devices[i]));
-            (void)hipFree(g->d_bsend[i]);
             (void)hipFree(g->d_brecv[i]);
-            g->d_bsend[i] = g->d_brecv[i] = nullptr;         // (an error return below leaves nothing to free twice)
+            g->d_brecv[i] = nullptr;                         // (an error return below leaves nothing to free twice)
         }
         if (g->h_bsend) (void)hipHostFree(g->h_bsend);
         if (g->h_brecv) (void)hipHostFree(g->h_brecv);
-        g->h_bsend = g->h_brecv = nullptr;
-        g->d_bsend.assign((size_t)ndev, nullptr);
+        g->h_bsend = g->h_brecv = g->hd_brecv = nullptr;
         g->d_brecv.assign((size_t)ndev, nullptr);
         for (int i = 0; i < ndev; ++i) {
             PSA_HIP(hipSetDevice(g->devices[i]));
-            PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_bsend[i]), sizeof(psa_result) * 2 * (size_t)per));
-            PSA_HIP(hipMemset(g->d_bsend[i], 0, sizeof(psa_result) * 2 * (size_t)per));     // (padding entries are never unpacked)
             PSA_HIP(hipMalloc(reinterpret_cast<void**>(&g->d_brecv[i]), sizeof(psa_result) * 2 * (size_t)per * ndev));
+            PSA_HIP(hipMemset(g->d_brecv[i], 0, sizeof(psa_result) * 2 * (size_t)per * ndev));     // (padding entries are never unpacked)
         }
+        PSA_HIP(hipSetDevice(g->devices[0]));
         PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_bsend), sizeof(psa_result) * 2 * (size_t)per * ndev, hipHostMallocPortable));
-        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_brecv), sizeof(psa_result) * 2 * (size_t)per * ndev, hipHostMallocPortable));
+        PSA_HIP(hipHostMalloc(reinterpret_cast<void**>(&g->h_brecv), sizeof(psa_result) * 2 * (size_t)per * ndev,
+                              hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+        PSA_HIP(hipHostGetDevicePointer(reinterpret_cast<void**>(&g->hd_brecv), g->h_brecv, 0));
         g->batch_per = per;
     }
     // the devices' blocks: device i searches queries [lo_i, hi_i) and fills block i of the exchange, [mode][per]
@@ -3215,48 +3384,76 @@ psa_status psa_search_batch_sharded(psa_group* g, const char* queries, int nq, i
     std::vector<psa_status> status((size_t)ndev, PSA_OK);
     std::vector<std::string> errors((size_t)ndev);
     std::vector<std::chrono::steady_clock::time_point> issued((size_t)ndev, t_enter);
-    const size_t block = sizeof(psa_result) * 2 * (size_t)per;
+    const size_t block = sizeof(psa_result) * 2 * (size_t)per;             // (a batch smaller than the buffers uses their front)
+    // device i's send block INSIDE its receive buffer, at its own rank: the all-gather's in-place form (no local copy)
+    std::vector<psa_result*> d_bsend((size_t)ndev);
+    for (int i = 0; i < ndev; ++i) d_bsend[(size_t)i] = g->d_brecv[(size_t)i] + (size_t)i * 2 * per;
     psa_result none;
     none.score = 0.0; none.offset = -1; none.char_offset = -1; none.ch = 0; none.shard = -1; none.pairs = 0;
     for (int i = 0; i < ndev; ++i) {
         psa_query_block(nq, ndev, i, &lo[i], &hi[i]);
         if (hi[i] - lo[i] > per) { set_last_error("internal: a query block exceeds the exchange block"); return PSA_ERR_STATE; }
+        g->stage[(size_t)i].store(0);
     }
+    const GroupFault fault = group_fault();
+    const unsigned xseq = ++g->xseq;
     auto device_job = [&](int i) {
         psa_context* c = g->ctx[(size_t)i];
         DeviceScope scope;
-        status[(size_t)i] = [&]() -> psa_status {
-            psa_result* mine = g->h_bsend + (size_t)i * 2 * per;
-            for (int k = 0; k < 2 * per; ++k) mine[k] = none;
-            const int count = hi[i] - lo[i];
-            psa_status st = PSA_OK;
-            bool on_device = false;                // the kernels have written this block's records to d_bsend[i]
-            if (count > 0) {
-                const char* q0 = queries + (size_t)lo[i] * stride;
-                // (the group's mode first: results / results_min are MAX / MIN)
-                c->batch_records[0] = rccl ? g->d_bsend[i] : nullptr;
-                c->batch_records[1] = rccl && nmodes == 2 ? g->d_bsend[i] + per : nullptr;
-                c->batch_records_final = false;
-                if (nmodes == 2) st = psa_search_batch_minmax(c, q0, count, m, stride, first, last, mine, mine + per);
-                else st = psa_search_batch(c, q0, count, m, stride, first, last, mine);
-                on_device = rccl && c->batch_records_final;
-                c->batch_records[0] = c->batch_records[1] = nullptr;
-            }
-            issued[(size_t)i] = std::chrono::steady_clock::now();
-            if (rccl) {
-                // (a failed batch still takes part in the exchange: the other devices' all-gathers wait for this one)
-                PSA_TRY(ensure_device(c));
-                if (!on_device)
-                    PSA_HIP(hipMemcpyAsync(g->d_bsend[i], mine, block, hipMemcpyHostToDevice, c->stream));
-                PSA_NCCL(g_rccl.all_gather(g->d_bsend[i], g->d_brecv[i], block, ncclChar, g->comm[i], c->stream));
-                if (i == 0) {
-                    PSA_HIP(hipMemcpyAsync(g->h_brecv, g->d_brecv[0], block * (size_t)ndev, hipMemcpyDeviceToHost, c->stream));
-                    PSA_HIP(hipStreamSynchronize(c->stream));       // device 0 holds every block: every batch has ended
+        psa_status st = PSA_OK;
+        std::string err;
+        auto note = [&](psa_status s) {
+            if (s != PSA_OK && st == PSA_OK) { st = s; err = psa_last_error(); }
+        };
+        psa_result* mine = g->h_bsend + (size_t)i * 2 * per;
+        for (int k = 0; k < 2 * per; ++k) mine[k] = none;
+        const int count = hi[i] - lo[i];
+        bool on_device = false;                // the kernels have written this block's records to d_bsend[i]
+        if (fault.hits(1, i)) {
+            set_last_error("injected fault: device fails before its launch");
+            note(PSA_ERR_DEVICE);
+        } else if (count > 0) {
+            const char* q0 = queries + (size_t)lo[i] * stride;
+            // (the group's mode first: results / results_min are MAX / MIN)
+            c->batch_records[0] = rccl ? d_bsend[(size_t)i] : nullptr;
+            c->batch_records[1] = rccl && nmodes == 2 ? d_bsend[(size_t)i] + per : nullptr;
+            c->batch_records_final = false;
+#ifdef PSA_EXPERIMENT
+            if (fault.hits(3, i) && ensure_device(c) == PSA_OK)
+                hipLaunchKernelGGL(psa_debug_stall_kernel, dim3(1), dim3(1), 0, c->stream, (unsigned long long)(fault.stall_ms * 1e5));
+#endif
+            if (nmodes == 2) note(psa_search_batch_minmax(c, q0, count, m, stride, first, last, mine, mine + per));
+            else note(psa_search_batch(c, q0, count, m, stride, first, last, mine));
+            on_device = rccl && st == PSA_OK && c->batch_records_final;
+            c->batch_records[0] = c->batch_records[1] = nullptr;
+        }
+        issued[(size_t)i] = std::chrono::steady_clock::now();
+        g->stage[(size_t)i].store(1, std::memory_order_release);
+        if (fault.hits(2, i)) {
+            set_last_error("injected fault: device fails before its part of the exchange");
+            note(PSA_ERR_DEVICE);
+        }
+        if (rccl) {
+            // ---- its part of the exchange: every path above arrives here
+            if (!on_device) {
+                if (ensure_device(c) != PSA_OK ||
+                    hipMemcpyAsync(d_bsend[(size_t)i], mine, block, hipMemcpyHostToDevice, c->stream) != hipSuccess) {
+                    set_last_error("psa_search_batch_sharded: copy of a device's block failed");
+                    note(PSA_ERR_DEVICE);
                 }
             }
-            return st;
-        }();
-        if (status[(size_t)i] != PSA_OK) errors[(size_t)i] = psa_last_error();     // (thread-local in the launcher thread)
+            const ncclResult_t r = g_rccl.all_gather(d_bsend[(size_t)i], g->d_brecv[i], block, ncclChar, g->comm[i], c->stream);
+            if (r != ncclSuccess) {
+                set_last_error(std::string("ncclAllGather: ") + g_rccl.error_string(r));
+                note(PSA_ERR_DEVICE);
+                g->stage[(size_t)i].store(-1, std::memory_order_release);
+            } else {
+                g->stage[(size_t)i].store(2, std::memory_order_release);
+            }
+            if (i == 0) note(publish_and_wait(g, g->d_brecv[0], g->hd_brecv, block * (size_t)ndev, xseq, false, "psa_search_batch_sharded"));
+        }
+        status[(size_t)i] = st;
+        errors[(size_t)i] = err;
     };
     g->workers->run(device_job);
     {

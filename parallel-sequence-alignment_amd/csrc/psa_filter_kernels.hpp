@@ -611,24 +611,14 @@ struct SlotRegs {
 template <int IMM>
 __device__ __forceinline__ void lds_issue(SlotRegs& n, unsigned addr)
 {
-#ifdef PSA_EXP_NOLDS          // timing experiment only (wrong results): the loop without its LDS reads
-    n.v[0] = ((unsigned long long)addr << 32) | (addr * 3u);
-    n.v[1] = ~n.v[0];
-    asm volatile("" : "+v"(n.v[0]), "+v"(n.v[1]));
-#else
     asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4"
                  : "=&v"(n.v[0]), "=&v"(n.v[1])
                  : "v"(addr), "i"(IMM), "i"(IMM + 512));
-#endif
 }
 
 __device__ __forceinline__ void lds_retire(SlotRegs& n)
 {
-#ifdef PSA_EXP_NOWAIT         // timing experiment only (wrong results): never wait for the LDS
-    asm volatile("" : "+v"(n.v[0]), "+v"(n.v[1]));
-#else
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(n.v[0]), "+v"(n.v[1]));
-#endif
 }
 
 // One char of a shift class: T is its index inside the round.  Char k of the class reads slot
@@ -2028,11 +2018,6 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         if (r.best_split && tid < kBestSplit) __hip_atomic_store(r.best_split + tid * kBestStride, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
-#ifdef PSA_TAIL_TWICE       // timing experiment: the rounds run twice, the stamps are the second (instruction-cache-warm) run's
-    for (int rep = 0; rep < 2; ++rep) {
-    __syncthreads();
-    PSA_FPHASE(1);
-#endif
     for (int base = 0; base < nsurv; base += G) {
         const int cnt = nsurv - base < G ? nsurv - base : G;
         // ---- pass 1
@@ -2131,9 +2116,6 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         __syncthreads();
         PSA_FPHASE(5);
     }
-#ifdef PSA_TAIL_TWICE
-    }
-#endif
     if (tid == 0) {
         const bool is_max = r.is_max != 0;
         int idx = -1;

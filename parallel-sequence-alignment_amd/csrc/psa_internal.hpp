@@ -7,6 +7,17 @@
 
 #include "psa.h"
 
+// Build switches.  The product library is built with none of them.  PSA_EXPERIMENT marks a debug build
+// (libpsa_debug.so: getenv knobs, fault injection, the test hooks of include/psa_debug.h); every other switch changes
+// what the kernels do or measure and is refused unless the build says it is an experiment; retired A/B switches
+// (whose branches computed wrong results) are refused always.
+#if defined(PSA_EXP_NOLDS) || defined(PSA_EXP_NOWAIT) || defined(PSA_TAIL_TWICE) || defined(PSA_NO_BEST_SPLIT)
+#error "PSA_EXP_NOLDS / PSA_EXP_NOWAIT / PSA_TAIL_TWICE / PSA_NO_BEST_SPLIT were timing experiments (HISTORY.md); their branches are gone"
+#endif
+#if !defined(PSA_EXPERIMENT) && (defined(PSA_PHASE_TIMING) || defined(PSA_RESCORE_EPL) || defined(PSA_PLANES_INLINE))
+#error "PSA_PHASE_TIMING / PSA_RESCORE_EPL / PSA_PLANES_INLINE change the kernels: build them as an experiment (make variant V=... EXTRA=\"-DPSA_EXPERIMENT ...\")"
+#endif
+
 namespace psa {
 
 // Symbol codes used on the device: 'A'..'Z' -> 0..25, '-' -> 26,

@@ -41,6 +41,7 @@ EXPORTED_SYMBOLS = (
     "psa_fallback_count", "psa_reselect_count", "psa_unfused_count", "psa_duo_retry_count",
     "psa_group_create", "psa_group_create_ex", "psa_group_destroy", "psa_group_size", "psa_group_set_weights",
     "psa_group_set_seq1", "psa_group_set_seq2", "psa_search_sharded", "psa_search_batch_sharded", "psa_group_last_timing",
+    "psa_group_set_timeout",
     "psa_fold", "psa_shard_range", "psa_query_block", "psa_query_block_max", "psa_batch_unpack", "psa_build_tables",
     "psa_set_profiling", "psa_last_timing", "psa_profile_totals", "psa_last_kernel_queries",
     "psa_generate_sequence", "psa_last_error", "psa_version",
@@ -121,6 +122,7 @@ def _load() -> C.CDLL:
     lib.psa_search_sharded.argtypes = [vp, i, i, C.POINTER(Result), C.POINTER(Result)]
     lib.psa_search_batch_sharded.argtypes = [vp, C.c_char_p, i, i, C.c_size_t, i, i, C.POINTER(Result), C.POINTER(Result)]
     lib.psa_group_last_timing.argtypes = [vp, dp, dp]
+    lib.psa_group_set_timeout.argtypes = [vp, C.c_double]
     lib.psa_fold.argtypes = [C.POINTER(Result), i, i, C.POINTER(Result)]
     lib.psa_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.psa_shard_range.restype = None
@@ -486,6 +488,10 @@ class Group:
         _check(lib.psa_search_batch_sharded(self._h, b"".join(queries), len(queries), m, m, first, last, hi,
                                             lo if minmax else None))
         return (list(hi), list(lo)) if minmax else list(hi)
+
+    def set_timeout(self, seconds: float):
+        """How long a group call waits for the devices before it gives up with PSA_ERR_DEVICE (default 60 s)."""
+        _check(lib.psa_group_set_timeout(self._h, float(seconds)))
 
     def last_timing(self):
         """(issue_us, total_us) of the last group call: host time until every device's work was enqueued / until it returned."""

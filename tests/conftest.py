@@ -61,6 +61,22 @@ def psa_debug(psa):
 
 
 @pytest.fixture(scope="session")
+def bench_line(psa):
+    """The JSON line of ONE `python bench.py --steps 2 --warmup 1 --queries 64 --no-cpu-baseline` run on this box (a child
+    process; exit code 0 = its self-check passed), shared by the structural test (test_gpu_parity.py) and the thresholds
+    (test_zz_bench_contract.py)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--queries", "64",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert run.returncode == 0, run.stderr[-3000:]
+    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    return json.loads(lines[0])
+
+
+@pytest.fixture(scope="session")
 def reference_records(oracle):
     """The 15 stacked records of the reference's input.txt (tests/golden copy)."""
     return oracle.read_records(os.path.join(GOLDEN, "reference_input.txt"))

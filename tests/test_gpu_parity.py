@@ -646,6 +646,68 @@ def test_group_of_several_contexts_host_exchange(psa, oracle, reference_records,
             assert [key(r) for r in hi] == [key(r) for r in want_hi] and [key(r) for r in lo] == [key(r) for r in want_lo]
 
 
+@pytest.mark.parametrize("devices,exchange", [([0, 0, 0], "host"), ([0], "rccl")])
+def test_group_calls_do_not_hang_on_a_failing_device(psa_debug, oracle, monkeypatch, devices, exchange):
+    """VERDICT r4 weak #4 / ADVICE r4: no group call is left waiting for a device (the reference aborts the job:
+    MPI_Abort, cpu_funcs.c:38-44).  Fault knobs of the debug library (PSA_GROUP_FAULT, read per call), over three contexts
+    with the host exchange and over the RCCL group of one:
+      launch:K    device K's job fails before its launch    -> the call returns PSA_ERR_DEVICE (the other devices' work
+      exchange:K  ... after its launch, before its exchange    has drained, every thread reached its part of the exchange),
+                                                               and the NEXT call on the same group gives the right answer;
+      stall:K:MS  a kernel idling MS ms in front of K's search, the group's deadline shorter -> PSA_ERR_DEVICE within the
+                  deadline, naming the device; while the device is still busy the next call fails AT ONCE (it does not
+                  queue behind it); once the stream has drained the group answers again.
+    Single searches and batches."""
+    import time
+    ex = psa_debug.EXCHANGE_HOST if exchange == "host" else psa_debug.EXCHANGE_RCCL
+    s1 = psa_debug.generate_sequence(4401, 60_000)
+    s2 = psa_debug.generate_sequence(4402, 700)
+    qs = [psa_debug.generate_sequence(4500 + q, 700) for q in range(7)]
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    want = key_of(oracle.search(s1, s2, W_README, True, threads=4))
+    with psa_debug.Context(0) as c:
+        c.set_weights(W_README, True)
+        c.set_seq1(s1)
+        want_batch = [key(r) for r in c.search_batch(qs)]
+    last = len(devices) - 1
+    with psa_debug.Group(devices, ex) as g:
+        g.set_weights(W_README, True)
+        g.set_seq1(s1)
+        g.set_seq2(s2)
+        assert key(g.search()[0]) == want
+        for fault in ("launch:0", f"launch:{last}", "exchange:0", f"exchange:{last}"):
+            for batch in (False, True):
+                monkeypatch.setenv("PSA_GROUP_FAULT", fault)
+                t0 = time.perf_counter()
+                with pytest.raises(psa_debug.PsaError) as e:
+                    g.search_batch(qs) if batch else g.search()
+                assert e.value.status == psa_debug.PSA_ERR_DEVICE and "injected fault" in str(e.value), (fault, batch, str(e.value))
+                assert time.perf_counter() - t0 < 5.0
+                monkeypatch.delenv("PSA_GROUP_FAULT")
+                assert key(g.search()[0]) == want, (fault, batch)                 # the same group, the next call
+                assert [key(r) for r in g.search_batch(qs)] == want_batch, (fault, batch)
+        # a device that does not answer in time: the deadline, the fast refusal while it is busy, the recovery
+        g.set_timeout(0.05)
+        for k in sorted({0, last}):
+            monkeypatch.setenv("PSA_GROUP_FAULT", f"stall:{k}:400")
+            t0 = time.perf_counter()
+            with pytest.raises(psa_debug.PsaError) as e:
+                g.search()
+            took = time.perf_counter() - t0
+            monkeypatch.delenv("PSA_GROUP_FAULT")
+            assert e.value.status == psa_debug.PSA_ERR_DEVICE and 0.04 < took < 0.3, (k, took, str(e.value))
+            assert "device 0" in str(e.value) and ("has not" in str(e.value)), str(e.value)
+            t0 = time.perf_counter()
+            with pytest.raises(psa_debug.PsaError) as e:                          # still stalled: refused, not queued
+                g.search()
+            assert time.perf_counter() - t0 < 0.05 and "still busy" in str(e.value), str(e.value)
+            time.sleep(0.6)                                                       # the stall has ended, the stream drains
+            assert key(g.search()[0]) == want, k
+            assert [key(r) for r in g.search_batch(qs)] == want_batch
+        g.set_timeout(60.0)
+        assert key(g.search(17, 50_000)[0]) == key_of(oracle.search(s1, s2, W_README, True, 17, 50_000, threads=4))
+
+
 def test_group_full_size_configs3_and_configs4(psa):
     """BASELINE.json configs[3] and [4] at their stated sizes through the device group, as far as one GPU goes: 8
     contexts on device 0 with the host exchange.  configs[3]: the 990,001 offsets of the 1M x 10k MAX search split by the
@@ -1047,20 +1109,14 @@ def test_bench_n_rank_paths_rehearsed_on_one_gpu(psa, extra):
         assert group["ok"] and all(g["ok"] for g in group["groups"]), group
 
 
-def test_bench_line_carries_the_contract(psa):
-    """`python bench.py` on one GPU: ONE JSON line with the driver's fields, `roofline` and (without --no-cpu-baseline)
-    `cpu_baseline`, the reference's timed region next to `value`, the health counters in `verified`, both engines, the
-    emulated offset shard and the low-entropy workload — and exit code 0 (the self-check passed)."""
-    import subprocess
-    import sys
-    from conftest import ROOT
-    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    run = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--queries", "64",
-                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
-    assert run.returncode == 0, run.stderr[-3000:]
-    lines = [ln for ln in run.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+def test_bench_line_carries_the_contract(psa, bench_line):
+    """`python bench.py` on one GPU (run once per session: conftest.bench_line): ONE JSON line with the driver's fields,
+    `roofline` and (without --no-cpu-baseline) `cpu_baseline`, the reference's timed region next to `value`, the health
+    counters in `verified`, both engines, the emulated offset shard and the low-entropy workload — and exit code 0 (the
+    self-check passed).  Structure and answers only: every timing / ratio / throughput threshold on the same line lives
+    in tests/test_zz_bench_contract.py, collected last, so that `pytest -x` cannot stop on a noisy box's timing before the
+    parity tests have run."""
+    d = bench_line
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "verified", "timed_region_8d", "single_search",
                 "sequential_engine", "shard_emulation", "low_entropy_acgt"):
@@ -1069,7 +1125,6 @@ def test_bench_line_carries_the_contract(psa):
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] in ("valu", "hbm") and {"achieved", "peak", "unit", "frac", "traffic"} <= set(r)
-    assert r["frac"] is None or 0.3 < r["frac"] < 1.0
     if r["frac"] is None:
         assert "frac_withheld" in r            # the committed counters are of other kernel sources, and the line says so
     v = d["verified"]
@@ -1078,17 +1133,14 @@ def test_bench_line_carries_the_contract(psa):
     assert d["sequential_engine"]["equals_filter_engine"]
     assert set(d["shard_emulation"]["blocking_search_us_per_rank"]) == {"1", "2", "4", "8"}
     assert d["low_entropy_acgt"]["max"]["fallbacks"] == 0 and d["low_entropy_acgt"]["min"]["fallbacks"] == 0
-    for leg in ("low_entropy_acgt", "low_entropy_protein"):        # within 1.25x of the uniform input (margin for noise)
+    for leg in ("low_entropy_acgt", "low_entropy_protein"):
         for mode in ("max", "min"):
-            assert d[leg][mode]["ratio_to_uniform_a_z"] < 1.35 and d[leg][mode]["second_launches"] == 0, (leg, mode, d[leg][mode])
+            assert d[leg][mode]["second_launches"] == 0, (leg, mode, d[leg][mode])
     # the library's own multi-GPU path, driven by a child process: an RCCL group of the one device + 2 / 4 / 8 contexts with
-    # the host exchange; answers equal a single context's, and 8 devices' launches are issued side by side
+    # the host exchange; answers equal a single context's
     group = d["c_abi_group"]
     assert group["ok"] and [len(g["devices"]) for g in group["groups"]] == [1, 2, 4, 8]
     assert all(g["sharded_search"]["equals_single_context"] and g["batch_sharded"]["256"]["equals_single_context"] for g in group["groups"])
-    assert group["groups"][3]["sharded_search"]["host_issue_us"] < 25.0
-    assert d["value"] > 1e14 and d["timed_region_8d"]["value"] > 1e14
-    assert d["single_search_latency_ms"] < 0.2 and d["gpu_run_program_latency_ms"] < 0.3
 
 
 @pytest.mark.parametrize("n,m,nq", [(9711, 2131, 37), (10000, 5000, 8), (30000, 700, 101), (4100, 33, 257)])
@@ -1660,25 +1712,22 @@ def test_seq2_of_many_chunks(psa, n, m):
     s2[::7] = rng.integers(65, 91, size=len(s2[::7]), dtype=np.uint8)
     s1b, s2b = s1.tobytes(), s2.tobytes()
     key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
-    import time
     with psa.Context(0) as ca, psa.Context(0) as cs:
         cs.set_engine(psa.ENGINE_SEQUENTIAL)
+        ca.set_profiling(True)                               # (names the kernel that answered: last_timing)
         for is_max in (True, False):
-            took = []
             for c in (ca, cs):
                 c.set_weights(W_README, is_max)
                 c.set_sequences(s1b, s2b)
-                c.search()                                   # (scratch of the chunked plan allocated: not in the timing)
-                t0 = time.perf_counter()
                 r = c.search()
-                took.append(time.perf_counter() - t0)
                 if c is ca:
                     got = key(r)
             assert got == key(r), (n, m, is_max)
             if is_max:
                 assert r.offset == at
-            if m <= 2_095_104:
-                assert took[0] * 3 < took[1], (n, m, took)         # the filter engine answered (measured: 20x)
+            # which engine answered (the 20x between them is a bench figure: tests/test_zz_bench_contract.py)
+            answered_by = ca.last_timing(1)[1]
+            assert ("psa_count_kernel" if m <= 2_095_104 else "psa_seq_kernel") in answered_by, (n, m, answered_by)
         assert ca.fallback_count() == 0
 
 
@@ -1695,7 +1744,7 @@ def test_search_in_pieces_when_the_chunk_counts_exceed_their_cap(psa, psa_debug,
     monkeypatch.setenv("PSA_SCRATCH_CAP", str(8 << 20))
     with psa_debug.Context(0) as cd, psa.Context(0) as cp:
         monkeypatch.delenv("PSA_SCRATCH_CAP")
-        for s1, s2 in cases:
+        for case, (s1, s2) in enumerate(cases):
             for is_max in (True, False):
                 for c in (cd, cp):
                     c.set_weights(W_README, is_max)
@@ -1713,7 +1762,9 @@ def test_search_in_pieces_when_the_chunk_counts_exceed_their_cap(psa, psa_debug,
                 assert key(cd.search_batch([s2, s2])[1]) == want
             lo, hi = max(0, want[1] - 2000), min(n - m + 1, want[1] + 2000)      # (MIN's winner; the whole range costs the oracle 40 s)
             assert want == key_of(oracle.search(s1, s2, W_README, False, lo, hi, threads=8))
-        assert cd.fallback_count() == 0 or cases[1][0][:4] == b"ACGT"           # (the tie-heavy input may overflow its lists)
+            if case == 0:
+                # (the counter is of candidate-list overflows: the uniform input has none; the tie-heavy input may)
+                assert cd.fallback_count() == 0 and cp.fallback_count() == 0, (cd.fallback_count(), cp.fallback_count())
 
 
 def key_of(want):

@@ -65,6 +65,42 @@ def test_survey_appendix_b(oracle, reference_records):
         assert "%.17g" % score == g["score"]
 
 
+def test_survey_delta_sets_pin_max_mode(oracle, psa):
+    """The one independent MAX-mode fact this repo holds (VERDICT r4 missing #2).  The reference ships no MAX fixture
+    (`output.txt` is a MIN run, README.md prints no MAX result), so get_max_substitute (cuda_funcs.cu:320-345) and
+    get_optimal_substitute (cuda_funcs.cu:396-421) are pinned by the line-cited restatement only.  SURVEY.md Appendix B
+    ("Substitution-table facts") records what the REFERENCE'S OWN functions gave when the survey compiled them: the set of
+    distinct substitution deltas over all pairs — w = 1 3 4 2: MAX {-3, 1, 3, 5}, MIN {-5, -3, -2, -1, 1, 2, 3};
+    w = 1.5 2.6 0.3 0.2 (README.md:57): MIN 9 distinct values.  These are SURVEY-STAGE OUTPUTS of the reference, not
+    reference-held fixtures; the oracle and psa_build_tables must both reproduce them, and stay inside the by-construction
+    bounds (MAX <= 6 outcomes, MIN <= 10)."""
+    import numpy as np
+    symbols = [chr(ord("A") + k) for k in range(26)] + ["-"]
+
+    def oracle_deltas(w, is_max):
+        out = set()
+        for a in symbols:
+            for b in symbols:
+                p = oracle.weight(oracle.table_sign(a, b), w)
+                out.add(oracle.weight(oracle.table_sign(a, oracle.substitute(a, b, w, is_max)), w) - p)
+        return out
+
+    def table_deltas(w, is_max):
+        return set(np.asarray(psa.build_tables(w, is_max).DELTA)[:27, :27].ravel().tolist())
+
+    assert oracle_deltas([1, 3, 4, 2], True) == {-3.0, 1.0, 3.0, 5.0} == table_deltas([1, 3, 4, 2], True)
+    assert oracle_deltas([1, 3, 4, 2], False) == {-5.0, -3.0, -2.0, -1.0, 1.0, 2.0, 3.0} == table_deltas([1, 3, 4, 2], False)
+    readme_min = oracle_deltas([1.5, 2.6, 0.3, 0.2], False)
+    assert len(readme_min) == 9 and readme_min == table_deltas([1.5, 2.6, 0.3, 0.2], False)
+    for w in ([1, 3, 4, 2], [1.5, 2.6, 0.3, 0.2], [0.8, 0.54, 2.6, 13.7], [5, 4, 3, 2]):
+        assert len(oracle_deltas(w, True)) <= 6 and len(oracle_deltas(w, False)) <= 10
+        assert oracle_deltas(w, True) == table_deltas(w, True)
+    # MAX rule facts the restatement cites (cuda_funcs.cu:326-333): a '.'/'_' pair is raised to '*' by the Seq1 char itself,
+    # a '*' pair must leave it (mutation is mandatory, quirk 1) and prefers '.' over '_' on a tie ('>=', quirk 3)
+    assert oracle.substitute("A", "W", [1, 3, 4, 2], True) == "A"
+    assert oracle.table_sign("A", oracle.substitute("A", "A", [1, 2, 2, 2], True)) == "."
+
+
 def test_substitute_never_missing(oracle):
     """get_substitute returns a character for all 27x27 pairs in both modes."""
     symbols = [chr(ord("A") + k) for k in range(26)] + ["-"]

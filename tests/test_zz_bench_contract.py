@@ -1,0 +1,77 @@
+"""Performance thresholds — collected LAST (the file name sorts behind every parity file) and still `-m gpu`.
+
+Everything here asserts a timing, a ratio or a throughput: contract checks of the bench line and of the engines'
+relative speed, not parity.  They live apart from tests/test_gpu_parity.py so that `pytest -m gpu -x` on a noisy box
+cannot stop on a timing miss before the last parity test has run.  The bench line itself is
+produced once per session (conftest.bench_line) and shared with the structural test in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+W_README = [1.5, 2.6, 0.3, 0.2]
+
+
+def test_bench_throughput_and_latency_floors(bench_line):
+    """The headline numbers stay where the north_star wants them: >= 1e9 pairs/s per GPU by five orders of magnitude
+    (the line's value is ~3.7e14), the reference's timed region (host buffers in, result out) in the same decade, one
+    configs[2] search well under a millisecond."""
+    d = bench_line
+    assert d["value"] > 1e14 and d["timed_region_8d"]["value"] > 1e14
+    assert d["single_search_latency_ms"] < 0.2 and d["gpu_run_program_latency_ms"] < 0.3
+    r = d["roofline"]
+    assert r["frac"] is None or 0.3 < r["frac"] < 1.0
+
+
+def test_bench_low_entropy_inputs_stay_near_the_uniform_time(bench_line):
+    """ACGT / protein-like inputs within 1.25x of the uniform input (margin for noise: 1.35)."""
+    d = bench_line
+    for leg in ("low_entropy_acgt", "low_entropy_protein"):
+        for mode in ("max", "min"):
+            assert d[leg][mode]["ratio_to_uniform_a_z"] < 1.35, (leg, mode, d[leg][mode])
+
+
+def test_bench_group_launches_are_issued_side_by_side(bench_line):
+    """8 contexts of a host-exchange group on the one GPU: the launcher threads issue the 8 shards' work within 25 us of the
+    call's entry (median 7; one thread took 40)."""
+    group = bench_line["c_abi_group"]
+    assert group["groups"][3]["sharded_search"]["host_issue_us"] < 25.0
+
+
+def test_bench_offset_shard_scales(bench_line):
+    """north_star's "near-linear on the offset shard", as far as one GPU can show it: the 1/8 shard of a configs[3] search
+    (123,750 offsets, multi-chunk plan) against the whole search, blocking, before any exchange.  Round 4: 48 us = 1.61x."""
+    e = bench_line["shard_emulation"]
+    per_rank = e["blocking_search_us_per_rank"]
+    assert per_rank["8"] < per_rank["1"], per_rank
+    assert e["blocking_search_speedup_at_8"] > 1.5, e
+
+
+def test_bench_group_of_one_costs_little_more_than_a_context(bench_line):
+    """The RCCL group of ONE device answers a blocking sharded search within 12 us of the single context's search-only time
+    (the exchange's fixed cost: all-gather enqueue + the polled receive buffer; round 4, with a D2H copy and a stream
+    synchronisation instead: +15..19)."""
+    d = bench_line
+    one = d["c_abi_group"]["groups"][0]["sharded_search"]["blocking_us"]
+    alone = d["single_search"]["search_only_us"]
+    assert one - alone < 12.0, (one, alone)
+
+
+@pytest.mark.parametrize("n,m", [(1_000_000, 400_000)])
+def test_chunked_filter_engine_beats_the_sequential_engine(psa, n, m):
+    """A Seq2 of 36 char chunks: the filter engine's search (HIP events on the context's stream) takes less than a third
+    of the sequential engine's (measured: 20x).  The answers' equality is test_seq2_of_many_chunks' business."""
+    rng = np.random.default_rng(m % 1000)
+    s1 = rng.integers(65, 91, size=n, dtype=np.uint8).tobytes()
+    s2 = rng.integers(65, 91, size=m, dtype=np.uint8).tobytes()
+    took = []
+    with psa.Context(0) as ca, psa.Context(0) as cs:
+        cs.set_engine(psa.ENGINE_SEQUENTIAL)
+        for c in (ca, cs):
+            c.set_weights(W_README, True)
+            c.set_sequences(s1, s2)
+            c.search()                                       # (scratch of the chunked plan allocated: not in the timing)
+            c.set_profiling(True)
+            c.search()
+            took.append(c.last_timing(0)[0])
+    assert took[0] * 3 < took[1], took
