@@ -205,6 +205,13 @@ psa_status psa_scores(psa_context* ctx, int first_offset, int last_offset,
  * redone by the sequential engine.  (The test hooks psa_debug_counts / psa_debug_rescore are not part of this
  * library: include/psa_debug.h, libpsa_debug.so.) */
 int psa_fallback_count(psa_context* ctx);
+/* Searches / batches of this context that the sequential engine (20x slower on such shapes) answered because the filter
+ * engine's per-chunk counts — a Seq2 of several char chunks over very many offsets — would have exceeded the context's
+ * cap on them: 16 GB, half of the device's free memory (looked up by the first search that asks for more than 256 MB),
+ * less after an allocation of them has failed (psa_scratch_shrink_count: a device without the memory makes such a
+ * search run in pieces or sequentially, not fail).  A blocking psa_search over the cap runs in pieces and is not counted. */
+int psa_scratch_fallback_count(psa_context* ctx);
+int psa_scratch_shrink_count(psa_context* ctx);
 /* Filter searches of this context whose candidate selection ran twice: candidates are picked
  * against a running bound while the tiles finish; when that overflows the list, the selection
  * is repeated against the final bound (only a second overflow goes to the sequential engine). */

@@ -433,6 +433,8 @@ struct SearchSlot {
     psa::BlockRec*      d_blocks = nullptr;    int blocks_cap = 0;      // sequential engine
     unsigned long long* d_partial = nullptr;   size_t partial_cap = 0;   // [nchunks][span_pad] counts of a multi-chunk search
     int*                d_arrivals = nullptr;  int arrivals_cap = 0;     // [ntiles], zero between searches
+    // shared combine of a fused multi-chunk search: per tile a "ready" tag, per (tile, chunk) a "claimed" tag (launch numbers)
+    int*                d_share = nullptr;
     Scalars*            d_scal = nullptr;
     unsigned long long* d_best_split = nullptr;   // kBestSplit words of the running bound, a cache line each (zero between searches)
     int*                d_cand = nullptr;
@@ -580,7 +582,14 @@ struct psa_context {
     // device groups: the final kernel of a single search also writes its 32-byte record here (device memory)
     psa_result* record_out = nullptr;
     int         record_shard = -1;
-    size_t      scratch_cap = (size_t)16 << 30;   // bytes of per-chunk counts one search may take (the debug library reads PSA_SCRATCH_CAP)
+    // bytes of per-chunk counts one search may take: at most 16 GB, and at most half of what the device had free when the
+    // context was created; lowered when an allocation of them fails (reserve_chunk_scratch).  Debug library: PSA_SCRATCH_CAP
+    size_t      scratch_cap = (size_t)16 << 30;
+    bool        share_combine = true;        // fused multi-chunk searches whose workgroups fit the CUs share the tiles' combine (debug library: PSA_SHARE=0)
+    int         share_spins = psa::kShareSpins;   // debug library: PSA_SHARE_SPINS=0 makes every waiting workgroup leave at once (the last arriver sweeps)
+    bool        scratch_cap_fitted = false;  // the device's free memory has been looked at (first request beyond 256 MB)
+    int         scratch_fallbacks = 0;       // searches / batches the sequential engine answered because their chunk counts exceed the cap
+    int         scratch_shrinks = 0;         // times the cap was lowered after a failed allocation
     // ... and the kernels that finish the queries of a batch write theirs here ([0]: the results / MAX block, [1]: the MIN
     // block of a MIN+MAX batch; device memory, query q at + q).  batch_records_final: the batch ended without the host
     // touching a result (no re-selection, no sequential-engine fallback), so the device blocks are what the host holds.
@@ -1348,6 +1357,23 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.class_chars = p.class_chars;
     a.lds_slots = p.lds_slots;
     a.tile_arrivals = s.d_arrivals;
+    a.share = 0;
+    a.share_spins = c->share_spins;
+    a.tile_ready = a.slice_claim = nullptr;
+    a.done_target = p.ntiles;
+    if (fused && inline_select && c->share_combine && p.nchunks > 1 && p.nchunks <= psa::kShareMaxChunks && p.ntiles <= psa::kShareMaxTiles &&
+        (long long)p.ntiles * p.nchunks <= c->cus) {
+        // (every chunk workgroup of every tile is resident at once: they share the tiles' combine + selection)
+        constexpr size_t kShareInts = (size_t)psa::kShareMaxTiles * (1 + psa::kShareMaxChunks);
+        if (!s.d_share) {
+            PSA_TRY(dev_alloc(&s.d_share, kShareInts));
+            PSA_HIP(hipMemsetAsync(s.d_share, 0, sizeof(int) * kShareInts, stream));     // (launch numbers start at 1)
+        }
+        a.share = 1;
+        a.tile_ready = s.d_share;
+        a.slice_claim = s.d_share + psa::kShareMaxTiles;
+        a.done_target = p.ntiles * p.nchunks;
+    }
     a.inline_select = inline_select ? 1 : 0;
     a.nmodes = s2 ? 2 : 1;
     a.cap = kCandCap;
@@ -1403,11 +1429,16 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
         a.raw_scan_from = base + 32 * ((p.ntiles - 1) * (psa::kTileStride / 32) + p.nchunks * p.class_chars + psa::kTile / 32 + 1);
         {
             // converter workgroups in front of the tiles: on the CUs the tiles leave free (at most 16), at least as many
-            // as keep a thread's share within kRawPerThread positions
+            // as keep a thread's share within kRawPerThread positions.  A search of a sub-range also has them validate the
+            // Seq1 bytes outside the tiles' windows (the tiles wait for the converters' arrival): one more converter per
+            // 128 KB of those, as far as the spare CUs go — 16 workgroups scanned 0.26 GB/ms, so the latency of a small
+            // range under a long Seq1 grew with n, not with the range.
             const long long tiles = (long long)p.ntiles * p.nchunks;
             const int need = (a.class_total + psa::kUnroll + 1024 * psa::kRawPerThread - 1) / (1024 * psa::kRawPerThread);
             const long long spare = (long long)c->cus - tiles;
-            int conv = (int)std::max<long long>(need, std::min<long long>(c->raw_converters, spare > 0 ? spare : 8));
+            const long long outside = (long long)base + std::max(0, raw->n - a.raw_scan_from);
+            const long long want = std::max<long long>(c->raw_converters, (outside + (128 << 10) - 1) / (128 << 10));
+            int conv = (int)std::max<long long>(need, std::min<long long>(want, spare > 0 ? spare : 8));
             a.raw_converters = conv;
             a.raw_expected = conv + (c->raw_force_timeout ? 1 : 0);
             a.raw_arrivals = c->d_raw_arrivals;
@@ -1525,6 +1556,14 @@ psa_status ensure_chunk_scratch(unsigned long long** partial, size_t* partial_ca
                                 const FilterPlan& p, hipStream_t stream)
 {
     const size_t need = (size_t)p.nchunks * p.ntiles * psa::kTile;
+#ifdef PSA_EXPERIMENT
+    // debug library: allocations of chunk counts beyond PSA_SCRATCH_ALLOC_FAIL_ABOVE bytes fail, as on a device without the memory
+    if (const char* r = std::getenv("PSA_SCRATCH_ALLOC_FAIL_ABOVE"))
+        if (need > *partial_cap && need * sizeof(unsigned long long) > (size_t)std::atoll(r)) {
+            set_last_error("injected fault: hipMalloc of the chunk counts fails");
+            return PSA_ERR_DEVICE;
+        }
+#endif
     if (need > *partial_cap) {
         *partial_cap = 0;
         PSA_TRY(dev_alloc(partial, need));
@@ -1619,6 +1658,54 @@ bool use_filter(const psa_context* c, int first, int last, int m)
     return t_filter < t_sequential;
 }
 
+// The chunk counts of the plan this search would use, allocated NOW if they are within the cap and not there yet — so that
+// a device without that much free memory is found out before the engine is chosen: a failed allocation lowers the cap
+// below the request (the search then runs in pieces or on the sequential engine, like any search over the cap) instead of
+// failing the search with PSA_ERR_DEVICE.  `ring`: the two ring buffers of a batch instead of the slot's own scratch.
+static void reserve_chunk_scratch(psa_context* c, int first, int last, int m, bool ring)
+{
+    if (c->engine == PSA_ENGINE_SEQUENTIAL || m < 1 || first >= last) return;
+    FilterPlan p;
+    if (!plan_filter(first, last, m, &p) || p.nchunks < 2) return;
+    const size_t bytes = chunk_scratch_bytes(p);
+    if (hipSetDevice(c->device) != hipSuccess) return;
+    if (!c->scratch_cap_fitted && bytes > ((size_t)256 << 20)) {
+        // (looked up once, by the first search that asks for much: psa_create stays as cheap as it is)
+        size_t free_bytes = 0, total_bytes = 0;
+        if (hipMemGetInfo(&free_bytes, &total_bytes) == hipSuccess) c->scratch_cap = std::min(c->scratch_cap, free_bytes / 2);
+        else (void)hipGetLastError();
+        c->scratch_cap_fitted = true;
+    }
+    if (bytes > c->scratch_cap) return;
+    bool ok = true;
+    if (ring) {
+        for (int k = 0; k < 2 && ok; ++k) {
+            size_t cap = c->ring_partial_cap;
+            int acap = c->ring_arrivals_cap;
+            ok = ensure_chunk_scratch(&c->d_ring_partial[k], &cap, &c->d_ring_arrivals[k], &acap, p, c->stream) == PSA_OK;
+            if (ok && k == 1) { c->ring_partial_cap = cap; c->ring_arrivals_cap = acap; }
+        }
+        if (!ok) c->ring_partial_cap = 0, c->ring_arrivals_cap = 0;     // (whatever half of the pair exists is re-made next time)
+    } else {
+        SearchSlot& s = c->slot[0];
+        ok = ensure_chunk_scratch(&s.d_partial, &s.partial_cap, &s.d_arrivals, &s.arrivals_cap, p, c->stream) == PSA_OK;
+    }
+    if (!ok) {
+        (void)hipGetLastError();                   // (the out-of-memory error is handled here)
+        c->scratch_cap = bytes > 1 ? bytes / 2 : 0;
+        c->scratch_shrinks += 1;
+    }
+}
+
+// The filter engine would take this search but for the cap on its chunk counts (health counter: psa_scratch_fallback_count)
+static bool capped_out(const psa_context* c, int first, int last, int m)
+{
+    if (c->engine == PSA_ENGINE_SEQUENTIAL) return false;
+    FilterPlan p;
+    return plan_filter(first, last, m, &p) && chunk_scratch_bytes(p) > c->scratch_cap;
+}
+
+
 // (seq1_args refuses it too; the host variants ask before they stage a gigabyte)
 psa_status check_seq1_length(int n)
 {
@@ -1693,6 +1780,7 @@ void free_slot(SearchSlot& s)
     (void)hipFree(s.d_blocks);
     (void)hipFree(s.d_partial);
     (void)hipFree(s.d_arrivals);
+    (void)hipFree(s.d_share);
     if (s.front_done) (void)hipEventDestroy(s.front_done);       // (scalars, candidate lists, records: the device arena)
     if (s.back_done) (void)hipEventDestroy(s.back_done);
 }
@@ -1832,11 +1920,19 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     if (const char* r = std::getenv("PSA_RAW_CONVERTERS")) c->raw_converters = std::max(1, std::min(1024, std::atoi(r)));
     if (const char* r = std::getenv("PSA_RAW_FORCE_TIMEOUT")) c->raw_force_timeout = std::atoi(r) != 0;
     if (const char* r = std::getenv("PSA_SELECT_FROZEN")) c->select_frozen = std::atoi(r) != 0;
+    if (const char* r = std::getenv("PSA_SHARE")) c->share_combine = std::atoi(r) != 0;
+    if (const char* r = std::getenv("PSA_SHARE_SPINS")) c->share_spins = std::max(0, std::atoi(r));
     if (const char* r = std::getenv("PSA_SCRATCH_CAP")) c->scratch_cap = (size_t)std::atoll(r);     // bytes; sends multi-chunk searches through the piece / sequential paths
 #endif
     *out = c;
     return PSA_OK;
 }
+
+// Searches / batches of this context that the sequential engine answered because the filter engine's per-chunk counts
+// would have exceeded the context's cap (16 GB, half of the device's free memory at psa_create, less after a failed
+// allocation), and how often a failed allocation lowered that cap.
+int psa_scratch_fallback_count(psa_context* c) { return c ? c->scratch_fallbacks : 0; }
+int psa_scratch_shrink_count(psa_context* c) { return c ? c->scratch_shrinks : 0; }
 
 void psa_destroy(psa_context* c)
 {
@@ -2012,7 +2108,9 @@ static psa_status search_async_impl(psa_context* c, int first, int last, psa_res
     c->record_shard = record_shard;
     if (c->profiling) PSA_HIP(hipEventRecord(c->ev[0], c->stream));
     c->last_kernel_queries = 1;
+    reserve_chunk_scratch(c, first, last, s.m, false);
     c->pending_filter = use_filter(c, first, last, s.m);
+    if (!c->pending_filter && capped_out(c, first, last, s.m)) c->scratch_fallbacks += 1;
     c->pending_first = first;
     c->pending_last = last;
     if (c->pending_filter) {
@@ -2200,6 +2298,7 @@ psa_status psa_search_device(psa_context* c, const void* d_seq1, int n, const vo
         return psa_search(c, first, last, out);
     };
     FilterPlan plan;
+    reserve_chunk_scratch(c, first, last, m, false);
     if (c->profiling || !use_filter(c, first, last, m) || !plan_filter(first, last, m, &plan) ||
         psa::fused_candidates_at_a_time(plan.lds_bytes, m) < 1)
         return two_launches();
@@ -2263,6 +2362,7 @@ static int piece_offsets(const psa_context* c, int first, int last)
 psa_status psa_search(psa_context* c, int first, int last, psa_result* out)
 {
     if (c && out && !c->pending && c->have_weights && c->n >= 0 && check_ready(c, c->slot[0].m, first, last) == PSA_OK) {
+        reserve_chunk_scratch(c, first, last, c->slot[0].m, false);
         const int piece = piece_offsets(c, first, last);
         if (piece > 0) {
             psa_result best;
@@ -2315,7 +2415,12 @@ static psa_status batch_once(psa_context* c, const void* d_queries, int nq, int 
     c->batch_records_final = false;
     PSA_TRY(ensure_tails(c, nq * nmodes));
     const unsigned char* base = static_cast<const unsigned char*>(d_queries);
+    {
+        FilterPlan whole;                         // (a batch of >= 2 queries prefers a plan without char chunks: nothing to reserve)
+        if (!(nq >= 2 && plan_filter(first, last, m, &whole, 1))) reserve_chunk_scratch(c, first, last, m, true);
+    }
     const bool filter = use_filter(c, first, last, m);
+    if (!filter && capped_out(c, first, last, m)) c->scratch_fallbacks += 1;
     const long long pairs = (long long)(last - first) * m;
     const int seq0 = c->seq + 1;
     c->timing_valid = false;
@@ -2658,6 +2763,10 @@ PSA_EXPORT int psa_debug_phase_ts(unsigned long long* out /* [1024][8] */)
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psa::g_phase_ts), sizeof(unsigned long long) * 1024 * 8);
 }
+PSA_EXPORT int psa_debug_chunk_ts(unsigned long long* out /* [1024][16] */)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(psa::g_chunk_ts), sizeof(unsigned long long) * 1024 * 16);
+}
 #endif
 
 #ifdef PSA_EXPERIMENT
@@ -2960,13 +3069,13 @@ static psa_status group_ready(psa_group* g)
     for (size_t i = 0; i < g->ctx.size(); ++i) {
         psa_context* c = g->ctx[i];
         PSA_TRY(ensure_device(c));
-        const hipError_t e = hipStreamQuery(c->stream);
-        if (e == hipErrorNotReady) {
+        // (a first hipStreamQuery of a stream nobody has waited on may say "not ready" for work that has ended — the
+        // runtime only then asks for its completion: look for a millisecond before calling the device busy)
+        if (!stream_idle_within(c->stream, 1e-3)) {
             set_last_error("device " + std::to_string(g->devices[i]) + " (shard " + std::to_string(i) +
                            ") is still busy with a group call that timed out");
             return PSA_ERR_DEVICE;
         }
-        if (e != hipSuccess) { set_last_error(std::string("hipStreamQuery: ") + hipGetErrorString(e)); return PSA_ERR_DEVICE; }
     }
     for (psa_context* c : g->ctx) {
         c->pending = false;

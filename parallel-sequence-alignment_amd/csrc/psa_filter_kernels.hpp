@@ -53,6 +53,7 @@ constexpr int kRowSlots = 1 << (kRowShift - 3);
 #ifdef PSA_PHASE_TIMING
 // debug build only: 100 MHz timestamps of the count kernel's phases, [block][phase]; rows 1000.. = re-score / tail
 __device__ unsigned long long g_phase_ts[1024][8];
+__device__ unsigned long long g_chunk_ts[1024][16];     // psa_count_kernel: sub-phases of the chunk hand-off and the selection (PSA_CPHASE)
 #define PSA_FPHASE(k) do { if (tid == 0) g_phase_ts[1002][k] = wall_clock64(); } while (0)
 #else
 #define PSA_FPHASE(k) do { } while (0)
@@ -2146,6 +2147,9 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
 }
 
 // ---- count kernel --------------------------------------------------------------
+constexpr int kShareMaxChunks = 32;       // chunk workgroups of a tile that may share its combine (one claim word each)
+constexpr int kShareMaxTiles = 256;       // ... of at most this many tiles (tiles x chunks <= the CUs)
+constexpr int kShareSpins = 16;           // polls (~2 us apart: a memory round trip + a short sleep) of a tile's "ready" tag before a chunk workgroup leaves
 struct CountArgs {
     const unsigned char* s1;        // Seq1 symbol codes, padded with kCodePad (32 per slot)
     const unsigned*      classes;   // Seq2 symbols as LDS row offsets (code << kRowShift) in class order (class_index)
@@ -2155,6 +2159,12 @@ struct CountArgs {
     int class_chars;  // chars of every shift class per chunk (multiple of kUnroll); a chunk = 32 x class_chars chars
     int lds_slots;    // slots per staged row (kTile/32 + class_chars + 1)
     int* tile_arrivals;   // [ntiles], zero between searches: chunk workgroups of a tile that have published their counts
+    // shared combine (fused single searches whose tiles x chunks fit the CUs): every chunk workgroup takes a slice of its tile
+    int  share;           // 0: the tile's last arriver combines and selects alone
+    int  share_spins;     // polls of the tile's "ready" tag before a workgroup leaves (debug library: 0 = leave at once)
+    int* tile_ready;      // [ntiles] the number of the launch whose chunk counts of this tile are complete
+    int* slice_claim;     // [ntiles][kShareMaxChunks] the number of the launch in which this slice was taken
+    int  done_target;     // arrivals on tail.done that end the search: tiles (x chunks when sharing)
     // single-chunk searches finish here: score bounds per offset, running best pessimistic
     // bound (atomic max), candidates = offsets whose optimistic bound reaches it.  The counts do
     // not depend on the search mode, so one pass can select for several modes (MAX and MIN of the
@@ -2202,8 +2212,10 @@ struct CountArgs {
 
 #ifdef PSA_PHASE_TIMING
 #define PSA_PHASE(k) do { if (tid == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1000) g_phase_ts[blockIdx.y * gridDim.x + blockIdx.x][k] = wall_clock64(); } while (0)
+#define PSA_CPHASE(k) do { if (tid == 0 && blockIdx.y * gridDim.x + blockIdx.x < 1000) g_chunk_ts[blockIdx.y * gridDim.x + blockIdx.x][k] = wall_clock64(); } while (0)
 #else
 #define PSA_PHASE(k) do { } while (0)
+#define PSA_CPHASE(k) do { } while (0)
 #endif
 
 template <int WAVES, bool RAW = false>
@@ -2223,7 +2235,6 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     // 128 tile workgroups — 128 arrivals on one counter under 244 pollers took 6 us to become visible.)
     const int conv_wgs = RAW ? a.raw_converters : 0;
     const int tile_x = (int)blockIdx.x - conv_wgs;
-    const int ntiles_x = (int)gridDim.x - conv_wgs;
     if constexpr (RAW) if (tile_x < 0) {
         if (blockIdx.y != 0) return;
         const int total = a.class_total + kUnroll;
@@ -2268,6 +2279,7 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
             const int hi_units = a.raw_scan_from < a.n1 ? (a.n1 - a.raw_scan_from + 15) >> 4 : 0;
             const bool aligned = ((reinterpret_cast<size_t>(a.raw1) | (size_t)a.raw_scan_from) & 15) == 0;
             bool any_bad = false;
+#pragma unroll 4
             for (int u = (int)blockIdx.x * WAVES * 64 + tid; u < lo_units + hi_units; u += conv_wgs * WAVES * 64) {
                 const int p0 = u < lo_units ? u << 4 : a.raw_scan_from + ((u - lo_units) << 4);
                 unsigned w[4];
@@ -2385,10 +2397,18 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     // each thread handles kTile / (WAVES*64) consecutive offsets of one word
     constexpr int kPer = kTile / (WAVES * 64);
     static_assert(kPer >= 1 && 16 % kPer == 0, "tile/threads");
-    const int o_local = tid * kPer;
+    int o_local = tid * kPer;
     unsigned n[kCounters][kPer];
     read_cells<kPer>(n, cells, kTileWords, o_local);
-    if (!a.inline_select || gridDim.y > 1) {
+    PSA_CPHASE(0);
+    __shared__ unsigned long long s_best[2][WAVES + 1];
+    __shared__ int s_flag;
+    __shared__ int s_last_tile;
+    const int nchunks = (int)gridDim.y;
+    const int tag = a.tail.seq;                         // this launch's number: what "ready" and "claimed" words must show
+    bool last_chunk = true;
+    if (!a.inline_select || nchunks > 1) {
+        // ---- several char chunks per tile (or psa_debug_counts): every chunk workgroup publishes its counts
         unsigned long long* dst = a.partial + (size_t)blockIdx.y * a.span_pad + (size_t)tile_x * kTile + o_local;
         // write-through (sc1) stores: they leave the XCD's L2 at once, so the hand-off below needs no L2 write-back
 #pragma unroll
@@ -2396,110 +2416,207 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
             __hip_atomic_store(dst + e, (unsigned long long)n[0][e] | ((unsigned long long)n[1][e] << 21) |
                                             ((unsigned long long)n[2][e] << 42), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!a.inline_select) return;
-        // Several char chunks per tile: the last chunk workgroup of the tile to arrive adds the others'
-        // counts to its own and goes on alone.  The chunk workgroups may sit on different XCDs (separate
-        // L2s).  Producer: every byte is stored sc1, every storing wave drains its stores (vmcnt(0)), the
-        // workgroup barrier, then ONE lane's arrival (MI355X_MICROARCH.md, "Valid forms": no release fence —
-        // an L2 write-back costs ~6 us per workgroup here).  Consumer: the last arriver's agent-scope acquire,
-        // barrier, agent-scope loads.
-        __shared__ int s_last_chunk;
+        // The chunk workgroups of a tile meet through memory; they may sit on different XCDs (separate L2s).  Producer:
+        // every byte is stored sc1, every storing wave drains its stores (vmcnt(0)), the workgroup barrier, then ONE
+        // lane's arrival (MI355X_MICROARCH.md, "Valid forms": no release fence — an L2 write-back costs ~6 us per
+        // workgroup here).  Consumer: agent-scope acquire behind the arrival counter (or the tile's "ready" tag), barrier,
+        // agent-scope loads.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PSA_CPHASE(1);
         __syncthreads();
+        PSA_CPHASE(2);
         if (tid == 0) {
             const int arrived = __hip_atomic_fetch_add(a.tile_arrivals + tile_x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_last_chunk = arrived == (int)gridDim.y - 1;
-            if (s_last_chunk) {
+            const int last = arrived == nchunks - 1;
+            s_flag = last;
+            if (last) {
                 __hip_atomic_store(a.tile_arrivals + tile_x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.share) __hip_atomic_store(a.tile_ready + tile_x, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             }
         }
+        PSA_CPHASE(3);
         __syncthreads();
-        if (!s_last_chunk) return;
-        for (int c = 0; c < (int)gridDim.y; ++c) {
-            if (c == (int)blockIdx.y) continue;
-            const unsigned long long* src = a.partial + (size_t)c * a.span_pad + (size_t)tile_x * kTile + o_local;
-#pragma unroll
-            for (int e = 0; e < kPer; ++e) {
-                const unsigned long long v = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                n[0][e] += (unsigned)(v & 0x1fffffu);
-                n[1][e] += (unsigned)((v >> 21) & 0x1fffffu);
-                n[2][e] += (unsigned)((v >> 42) & 0x1fffffu);
+        PSA_CPHASE(4);
+        last_chunk = __builtin_amdgcn_readfirstlane(s_flag) != 0;
+        if (!last_chunk) {
+            // Without sharing the tile's last chunk workgroup to arrive adds the others' counts to its own and goes on
+            // alone (plans of more workgroups than CUs, batches: the others have no reason to be resident still).
+            if (!a.share) return;
+            // sharing: wait — with a bound — for the tile's "ready" tag
+            __syncthreads();
+            if (tid == 0) {
+                int seen = 0;
+                for (int spins = 0; spins < a.share_spins; ++spins) {
+                    if (__hip_atomic_load(a.tile_ready + tile_x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) { seen = 1; break; }
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                if (seen) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                s_flag = seen;
             }
+            __syncthreads();
+            if (!__builtin_amdgcn_readfirstlane(s_flag)) return;     // gave up: the tile's last arriver takes this slice
         }
     }
-    // the counts are final
-    PSA_PHASE(5);
-    __shared__ unsigned long long s_best[2][WAVES + 1];
-    double up[2][kPer];
-    for (int mode = 0; mode < a.nmodes; ++mode) {
-        // offsets relative to the range's first one; the tile answers for its first kTileStride positions
-        const double pess = thread_bounds<kPer>(a.sel[mode].bounds, n, tile_x * kTileStride + o_local - a.lead,
-                                                a.span, kTileStride - o_local, up[mode]);
-        unsigned long long key = order_key(pess);
-        key = wave_max_u64(key);
-        if (lane == 0) s_best[mode][wave] = key;
-    }
-    __syncthreads();
-    if (tid < a.nmodes) {
-        // running best over the tiles finished so far: a lower bound of the final best, so selecting against it
-        // keeps a superset of the true candidates (whoever re-scores re-checks against the final bound)
-        unsigned long long key = s_best[tid][0];
-        for (int w = 1; w < WAVES; ++w) key = s_best[tid][w] > key ? s_best[tid][w] : key;
-#ifdef PSA_PHASE_TIMING
-        if (tid == 0 && blockIdx.x < 244) g_phase_ts[700 + blockIdx.x][0] = wall_clock64();
-#endif
-        unsigned long long old;
-        if (a.fused && a.tail.best_split) {
-            // (fused: one mode.  In a re-selection launch every word starts from the first pass's final bound.)
-            old = atomicMax(a.tail.best_split + (tile_x & (kBestSplit - 1)) * kBestStride, key);
+    // ---- SHARED COMBINE (a fused single search whose tiles x chunks fit the GPU's CUs: an offset shard).  One workgroup
+    // adding up (C - 1) x 32 KB of other workgroups' counts is bound by what ONE CU keeps in flight (measured, 5 chunks:
+    // 3 us for its first wave + 5.4 us until its last, then bounds and selection for all 4064 offsets alone) while the
+    // tile's other C - 1 CUs have gone idle.  Instead every chunk workgroup waits for the tile's "ready" tag (the last
+    // arriver's store) and takes the C-th part of the tile's offsets — slice c = blockIdx.y: its own counts from LDS, the
+    // others' from memory, bounds, selection, and its own arrival on the search's counter (done_target = tiles x chunks).
+    // NOBODY WAITS WITHOUT A BOUND: a workgroup that does not see the tag within share_spins polls leaves (its peers are
+    // not resident: the GPU is shared).  Every slice has a "claimed" word (atomic exchange with the launch's tag: exactly
+    // one taker); the tile's last arriver, which waits for nobody, takes its own slice and then every slice it finds
+    // unclaimed — so each slice is processed exactly once whoever left, and no word needs zeroing between launches.
+    // Without sharing there is one "slice": the whole tile, this workgroup's.
+    const bool sharing = nchunks > 1 && a.share != 0;
+    const int nslices = sharing ? nchunks : 1;
+    const int groups = (sharing ? kTileStride : kTile) / kPer;           // groups of kPer offsets that are dealt out
+    int* const claim = a.slice_claim + (size_t)tile_x * kShareMaxChunks;
+    bool finish = false;
+#pragma unroll 1
+    for (int pass = 0; pass < 2; ++pass) {
+        unsigned long long mine = 1ull;
+        if (!sharing) {
+            if (pass == 1) break;
         } else {
-            old = atomicMax(a.sel[tid].global_best, key);
+            if (pass == 1 && !last_chunk) break;
+            // its own slice; the last arriver then asks for all the others.  One lane per wanted slice exchanges its
+            // "claimed" word, all at once
+            const unsigned long long todo = pass == 0 ? 1ull << blockIdx.y : ((1ull << nchunks) - 1ull) & ~(1ull << blockIdx.y);
+            __syncthreads();
+            if (wave == 0) {
+                const bool want = lane < nchunks && ((todo >> lane) & 1ull);
+                int old = tag;
+                if (want) old = __hip_atomic_exchange(claim + lane, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long got = __ballot(want && old != tag);
+                if (lane == 0) s_best[0][WAVES] = got;
+            }
+            __syncthreads();
+            const unsigned long long got = s_best[0][WAVES];
+            mine = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)got) |
+                   ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(got >> 32)) << 32);
+            __syncthreads();
         }
-        s_best[tid][WAVES] = old > key ? old : key;
-#ifdef PSA_PHASE_TIMING
-        if (tid == 0 && blockIdx.x < 244) g_phase_ts[700 + blockIdx.x][1] = wall_clock64();
-#endif
-    }
-    __syncthreads();
-    for (int mode = 0; mode < a.nmodes; ++mode) {
-        const CountArgs::CountSelect& sel = a.sel[mode];
-        double need = key_order(s_best[mode][WAVES]);
-#ifdef PSA_EXPERIMENT
-        if (a.select_frozen) need = -1.7976931348623157e308;    // every real offset is a candidate (not the -inf of the others)
-#endif
+#pragma unroll 1
+        while (mine) {
+            const int slice = __builtin_ctzll(mine);
+            mine &= mine - 1ull;
+            const int g0 = slice * groups / nslices, g1 = (slice + 1) * groups / nslices;
+            const bool active = tid < g1 - g0;
+            o_local = (active ? g0 + tid : g0) * kPer;
+            read_cells<kPer>(n, cells, kTileWords, o_local);
+            if (nchunks > 1) {
+                // the other chunks' counts of this thread's kPer offsets.  The loads of kCombineAhead chunks are all issued
+                // before the first is used (a slot beyond the last chunk reads this workgroup's own counts and is masked
+                // out: straight-line code, no branch between the loads).  A rolled loop waited one memory round trip per
+                // chunk, 1.7 us each: the planner's former "chunk term".
+                constexpr int kCombineAhead = 4;
+                const int nothers = nchunks - 1;
+                const unsigned long long* const at = a.partial + (size_t)tile_x * kTile + o_local;
+                for (int j0 = 0; j0 < nothers; j0 += kCombineAhead) {
+                    unsigned long long v[kCombineAhead][kPer];
 #pragma unroll
-        for (int e = 0; e < kPer; ++e)
-            if (up[mode][e] >= need) {
-                const int slot = atomicAdd(sel.cand_count, 1);
-                if (slot < a.cap) {
-                    store_agent(sel.cand + slot, a.first + tile_x * kTileStride + o_local + e - a.lead);
-                    store_agent(sel.cand_upper + slot, up[mode][e]);
+                    for (int j = 0; j < kCombineAhead; ++j) {
+                        const bool take = j0 + j < nothers;
+                        const int c = j0 + j < (int)blockIdx.y ? j0 + j : j0 + j + 1;      // the chunks but this one, in order
+                        const unsigned long long* src = at + (size_t)(take ? c : (int)blockIdx.y) * a.span_pad;
+#pragma unroll
+                        for (int e = 0; e < kPer; ++e) {
+                            v[j][e] = __hip_atomic_load(src + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            v[j][e] = take ? v[j][e] : 0ull;
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < kCombineAhead; ++j)
+#pragma unroll
+                        for (int e = 0; e < kPer; ++e) {
+                            n[0][e] += (unsigned)(v[j][e] & 0x1fffffu);
+                            n[1][e] += (unsigned)((v[j][e] >> 21) & 0x1fffffu);
+                            n[2][e] += (unsigned)((v[j][e] >> 42) & 0x1fffffu);
+                        }
                 }
             }
-    }
-    PSA_PHASE(6);
-    if (!a.fused) return;
-    // ---- a single search ends in this launch: the last tile workgroup to get here finishes it.  Producer side of
-    // the hand-off: the candidate stores above are write-through, every wave drains its own, the workgroup
-    // barrier, then ONE lane's arrival; the last arriver acquires.
-    __shared__ int s_last_tile;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // (finish_search's survivor counter: the plane rows / exchange area it lies in are dead since the counter sums)
-    if (tid == 0) *reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + kFusedCounterOffset) = 0;
-    __syncthreads();
-    if (tid == 0) {
+            // the counts are final
+            PSA_PHASE(5);
+            PSA_CPHASE(5);
+            const int valid = active ? kTileStride - o_local : 0;
+            double up[2][kPer];
+            for (int mode = 0; mode < a.nmodes; ++mode) {
+                // offsets relative to the range's first one; the tile answers for its first kTileStride positions
+                const double pess = thread_bounds<kPer>(a.sel[mode].bounds, n, tile_x * kTileStride + o_local - a.lead,
+                                                        a.span, valid, up[mode]);
+                unsigned long long key = order_key(pess);
+                key = wave_max_u64(key);
+                if (lane == 0) s_best[mode][wave] = key;
+            }
+            PSA_CPHASE(6);
+            __syncthreads();
+            PSA_CPHASE(7);
+            if (tid < a.nmodes) {
+                // running best over the tiles finished so far: a lower bound of the final best, so selecting against it
+                // keeps a superset of the true candidates (whoever re-scores re-checks against the final bound)
+                unsigned long long key = s_best[tid][0];
+                for (int w = 1; w < WAVES; ++w) key = s_best[tid][w] > key ? s_best[tid][w] : key;
 #ifdef PSA_PHASE_TIMING
-        if (blockIdx.x < 244) g_phase_ts[700 + blockIdx.x][2] = wall_clock64();
+                if (tid == 0 && blockIdx.x < 244) g_phase_ts[700 + blockIdx.x][0] = wall_clock64();
 #endif
-        const int arrived = __hip_atomic_fetch_add(a.tail.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last_tile = arrived == ntiles_x - 1;
+                unsigned long long old;
+                if (a.fused && a.tail.best_split) {
+                    // (fused: one mode.  In a re-selection launch every word starts from the first pass's final bound.)
+                    old = atomicMax(a.tail.best_split + (tile_x & (kBestSplit - 1)) * kBestStride, key);
+                } else {
+                    old = atomicMax(a.sel[tid].global_best, key);
+                }
+                s_best[tid][WAVES] = old > key ? old : key;
 #ifdef PSA_PHASE_TIMING
-        if (blockIdx.x < 244) { g_phase_ts[700 + blockIdx.x][3] = wall_clock64(); g_phase_ts[700 + blockIdx.x][4] = (unsigned long long)arrived; }
+                if (tid == 0 && blockIdx.x < 244) g_phase_ts[700 + blockIdx.x][1] = wall_clock64();
 #endif
-        if (s_last_tile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            PSA_CPHASE(8);
+            __syncthreads();
+            PSA_CPHASE(9);
+            for (int mode = 0; mode < a.nmodes; ++mode) {
+                const CountArgs::CountSelect& sel = a.sel[mode];
+                double need = key_order(s_best[mode][WAVES]);
+#ifdef PSA_EXPERIMENT
+                if (a.select_frozen) need = -1.7976931348623157e308;    // every real offset is a candidate (not the -inf of the others)
+#endif
+#pragma unroll
+                for (int e = 0; e < kPer; ++e)
+                    if (up[mode][e] >= need) {
+                        const int slot = atomicAdd(sel.cand_count, 1);
+                        if (slot < a.cap) {
+                            store_agent(sel.cand + slot, a.first + tile_x * kTileStride + o_local + e - a.lead);
+                            store_agent(sel.cand_upper + slot, up[mode][e]);
+                        }
+                    }
+            }
+            PSA_PHASE(6);
+            if (!a.fused) return;
+            // ---- a single search ends in this launch: the last of `done_target` selections to get here finishes it.
+            // Producer side of the hand-off: the candidate stores above are write-through, every wave drains its own, the
+            // workgroup barrier, then ONE lane's arrival; the last arriver acquires.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (finish_search's survivor counter: the plane rows / exchange area it lies in are dead since the counter sums)
+            if (tid == 0) *reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(lds) + kFusedCounterOffset) = 0;
+            __syncthreads();
+            if (tid == 0) {
+#ifdef PSA_PHASE_TIMING
+                if (blockIdx.x < 244) g_phase_ts[700 + blockIdx.x][2] = wall_clock64();
+#endif
+                const int arrived = __hip_atomic_fetch_add(a.tail.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last_tile = arrived == a.done_target - 1;
+#ifdef PSA_PHASE_TIMING
+                if (blockIdx.x < 244) { g_phase_ts[700 + blockIdx.x][3] = wall_clock64(); g_phase_ts[700 + blockIdx.x][4] = (unsigned long long)arrived; }
+#endif
+                if (s_last_tile) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            finish = __builtin_amdgcn_readfirstlane(s_last_tile) != 0 || finish;
+        }
     }
-    __syncthreads();
-    if (!s_last_tile) return;
+    if (!finish) return;
     finish_search<WAVES, RAW>(a.tail, reinterpret_cast<unsigned char*>(lds), a.lds_bytes, tid);
     PSA_PHASE(7);
 }

@@ -39,6 +39,7 @@ EXPORTED_SYMBOLS = (
     "psa_search_batch", "psa_search_batch_device",
     "psa_search_batch_minmax", "psa_search_batch_minmax_device",
     "psa_fallback_count", "psa_reselect_count", "psa_unfused_count", "psa_duo_retry_count",
+    "psa_scratch_fallback_count", "psa_scratch_shrink_count",
     "psa_group_create", "psa_group_create_ex", "psa_group_destroy", "psa_group_size", "psa_group_set_weights",
     "psa_group_set_seq1", "psa_group_set_seq2", "psa_search_sharded", "psa_search_batch_sharded", "psa_group_last_timing",
     "psa_group_set_timeout",
@@ -108,6 +109,8 @@ def _load() -> C.CDLL:
         lib.psa_debug_counts.argtypes = [vp, i, i, vp, vp, vp]
         lib.psa_debug_rescore.argtypes = [vp, vp, i, vp]
     lib.psa_fallback_count.argtypes = [vp]
+    lib.psa_scratch_fallback_count.argtypes = [vp]
+    lib.psa_scratch_shrink_count.argtypes = [vp]
     lib.psa_reselect_count.argtypes = [vp]
     lib.psa_duo_retry_count.argtypes = [vp]
     lib.psa_unfused_count.argtypes = [vp]
@@ -404,6 +407,14 @@ class Context:
 
     def fallback_count(self) -> int:
         return lib.psa_fallback_count(self._h)
+
+    def scratch_fallback_count(self) -> int:
+        """Searches / batches answered by the sequential engine because their per-chunk counts exceed the context's cap."""
+        return lib.psa_scratch_fallback_count(self._h)
+
+    def scratch_shrink_count(self) -> int:
+        """Times a failed allocation of per-chunk counts lowered that cap."""
+        return lib.psa_scratch_shrink_count(self._h)
 
     def duo_retry_count(self) -> int:
         """Batches redone without the batch count kernel after one of its group barriers timed out."""

@@ -684,8 +684,10 @@ def test_group_calls_do_not_hang_on_a_failing_device(psa_debug, oracle, monkeypa
                 assert e.value.status == psa_debug.PSA_ERR_DEVICE and "injected fault" in str(e.value), (fault, batch, str(e.value))
                 assert time.perf_counter() - t0 < 5.0
                 monkeypatch.delenv("PSA_GROUP_FAULT")
+                g.set_seq2(s2)                                                    # (a batch replaces the contexts' Seq2)
                 assert key(g.search()[0]) == want, (fault, batch)                 # the same group, the next call
                 assert [key(r) for r in g.search_batch(qs)] == want_batch, (fault, batch)
+                g.set_seq2(s2)
         # a device that does not answer in time: the deadline, the fast refusal while it is busy, the recovery
         g.set_timeout(0.05)
         for k in sorted({0, last}):
@@ -704,6 +706,7 @@ def test_group_calls_do_not_hang_on_a_failing_device(psa_debug, oracle, monkeypa
             time.sleep(0.6)                                                       # the stall has ended, the stream drains
             assert key(g.search()[0]) == want, k
             assert [key(r) for r in g.search_batch(qs)] == want_batch
+            g.set_seq2(s2)
         g.set_timeout(60.0)
         assert key(g.search(17, 50_000)[0]) == key_of(oracle.search(s1, s2, W_README, True, 17, 50_000, threads=4))
 
@@ -1665,6 +1668,60 @@ def test_long_seq2_multi_chunk_path(psa, psa_debug, oracle):
             assert c.fallback_count() == 0
 
 
+def test_offset_shards_share_the_tiles_combine(psa, psa_debug, monkeypatch):
+    """A fused multi-chunk search whose tiles x chunks fit the CUs (an offset shard of configs[3]; a few tiles under a long
+    Seq2): every chunk workgroup of a tile takes a slice of the tile's offsets once the tile's last arriver has tagged it
+    ready (psa_count_kernel, "shared combine").  Three builds of the same search must agree with the sequential engine (the
+    independent kernel), both modes, single searches and one-shot searches from raw ASCII:
+      product             waiting workgroups see the tag and take their slices;
+      PSA_SHARE_SPINS=0   (debug library) every waiting workgroup leaves at once: the last arrivers sweep all slices alone —
+                          what happens when a tile's workgroups are not resident together (a shared GPU);
+      PSA_SHARE=0         (debug library) the path of plans with more workgroups than CUs: the last arriver does the tile.
+    Shapes: 1/2, 1/4, 1/8 of the 990,001 offsets (61 x 3, 31 x 5 ... workgroups), ranges of one to six tiles (up to ten
+    chunks), odd starts, a tie-heavy input (candidate-list overflow -> the re-selection launch shares as well)."""
+    import torch
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    n, m = 1_000_000, 10_000
+    total = n - m + 1
+    s1, s2 = psa.generate_sequence(1002, n), psa.generate_sequence(2002, m)
+    ranges = [psa.shard_range(total, w, r) for w, r in ((2, 1), (4, 0), (4, 3), (8, 0), (8, 5), (8, 7))]
+    ranges += [(0, 4000), (4063, 8200), (777_001, 777_001 + 3 * 4064 + 5), (500_000, 500_000 + 6 * 4064), (990_000, 990_001), (5, 37)]
+    monkeypatch.setenv("PSA_SHARE_SPINS", "0")
+    sweep = psa_debug.Context(0)
+    monkeypatch.delenv("PSA_SHARE_SPINS")
+    monkeypatch.setenv("PSA_SHARE", "0")
+    alone = psa_debug.Context(0)
+    monkeypatch.delenv("PSA_SHARE")
+    t1 = torch.frombuffer(bytearray(s1), dtype=torch.uint8).cuda()
+    t2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
+    torch.cuda.synchronize()
+    with psa.Context(0) as cp, psa.Context(0) as cs, sweep, alone:
+        cs.set_engine(psa.ENGINE_SEQUENTIAL)
+        for is_max in (True, False):
+            for c in (cp, cs, sweep, alone):
+                c.set_weights(W_README, is_max)
+                c.set_sequences(s1, s2)
+            for lo, hi in ranges:
+                want = key(cs.search(lo, hi))
+                for c in (cp, sweep, alone):
+                    assert key(c.search(lo, hi)) == want, (is_max, lo, hi, c is cp, c is sweep)
+                    assert key(c.search(lo, hi)) == want                     # (twice: the tags of the previous launch are stale, not zero)
+                assert key(cp.search_device(t1.data_ptr(), n, t2.data_ptr(), m, lo, hi)) == want, (is_max, lo, hi, "one-shot")
+                assert key(sweep.search_device(t1.data_ptr(), n, t2.data_ptr(), m, lo, hi)) == want, (is_max, lo, hi, "one-shot, sweep")
+                for c in (cp, sweep):
+                    c.set_sequences(s1, s2)
+        assert cp.fallback_count() == 0 and sweep.fallback_count() == 0 and alone.fallback_count() == 0
+        # ties: every 4th offset of an ACGT repeat scores alike -> the lists overflow, the selection runs again (shared too)
+        r1, r2 = b"ACGT" * 60_000, b"ACGT" * 3000
+        for c in (cp, cs, sweep, alone):
+            c.set_weights(W_README, True)
+            c.set_sequences(r1, r2)
+        for lo, hi in ((0, 30_000), (1001, 99_000)):
+            want = key(cs.search(lo, hi))
+            for c in (cp, sweep, alone):
+                assert key(c.search(lo, hi)) == want, (lo, hi)
+
+
 @pytest.mark.parametrize("n,m", [(200_000, 70_000), (150_000, 33_000), (120_000, 16_400)])
 def test_very_long_seq2_tail_paths(psa, n, m):
     """The search's tail beyond its usual shape: |Seq2| >= 65,536 (no certificate: the survivors are classified and
@@ -1765,6 +1822,33 @@ def test_search_in_pieces_when_the_chunk_counts_exceed_their_cap(psa, psa_debug,
             if case == 0:
                 # (the counter is of candidate-list overflows: the uniform input has none; the tie-heavy input may)
                 assert cd.fallback_count() == 0 and cp.fallback_count() == 0, (cd.fallback_count(), cp.fallback_count())
+
+
+def test_chunk_counts_that_cannot_be_allocated_lower_the_cap(psa, psa_debug, monkeypatch):
+    """the cap on a search's per-chunk counts used to be a fixed 16 GB whatever the device had free, and a failed
+    hipMalloc of them failed the search.  Now the counts are allocated before the engine is chosen, and a failure (debug
+    library: PSA_SCRATCH_ALLOC_FAIL_ABOVE) lowers the cap below the request: the blocking search runs in pieces, the async /
+    batch entry points answer with the sequential engine and say so (psa_scratch_fallback_count) — same answers as the
+    product library's unsplit filter search, no PSA_ERR_DEVICE."""
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    n, m = 700_000, 30_000                     # 3+ chunks, 165 tiles: 16+ MB of chunk counts
+    s1, s2 = psa.generate_sequence(881, n), psa.generate_sequence(882, m)
+    monkeypatch.setenv("PSA_SCRATCH_ALLOC_FAIL_ABOVE", str(8 << 20))
+    with psa_debug.Context(0) as cd, psa.Context(0) as cp:
+        for c in (cd, cp):
+            c.set_weights(W_README, True)
+            c.set_sequences(s1, s2)
+        want = key(cp.search())
+        assert cd.scratch_shrink_count() == 0
+        assert key(cd.search()) == want                         # allocation fails -> cap lowered -> in pieces
+        assert cd.scratch_shrink_count() >= 1 and cd.scratch_fallback_count() == 0
+        shrinks = cd.scratch_shrink_count()
+        assert key(cd.search()) == want and cd.scratch_shrink_count() == shrinks      # (the lowered cap is remembered)
+        cd.search_async(0, n - m + 1)                           # not in pieces: the sequential engine, counted
+        assert key(cd.search_wait()) == want and cd.scratch_fallback_count() == 1
+        assert key(cd.search(1000, 20_000)) == key(cp.search(1000, 20_000))           # a small range still fits: filter engine
+        assert cd.scratch_fallback_count() == 1 and cd.fallback_count() == 0
+        assert cp.scratch_shrink_count() == 0 and cp.scratch_fallback_count() == 0
 
 
 def key_of(want):
