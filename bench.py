@@ -297,16 +297,6 @@ def group_leg_main(args):
     nq_big = 256 if (n, m) == (1_000_000, 10_000) else min(256, args.queries or 256)
     hq = [psa.generate_sequence_np(SEED_QUERY0 + q, m).tobytes() for q in range(nq_big)]
 
-    # the single-context answers
-    with psa.Context(0) as ctx:
-        ctx.set_weights(WEIGHTS, True)
-        ctx.set_seq1(h1)
-        ctx.set_seq2(hq[0])
-        ref0 = ctx.search(0, total)
-        ref_batch = ctx.search_batch(hq)
-        ref_hi, ref_lo = ctx.search_batch_minmax(hq[:64])
-    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
-
     def wall_us(fn, reps, warm=3):
         t = []
         for k in range(reps + warm):
@@ -315,6 +305,20 @@ def group_leg_main(args):
             if k >= warm:
                 t.append(time.perf_counter() - t0)
         return 1e6 * sorted(t)[len(t) // 2]
+
+    # the single-context answers; and what ONE blocking search costs a single context in this process, called the same way
+    # the groups are timed below (the bare C entry point, result buffers allocated beforehand): the exchange's cost is the
+    # difference to a group's `c_call_us`
+    with psa.Context(0) as ctx:
+        ctx.set_weights(WEIGHTS, True)
+        ctx.set_seq1(h1)
+        ctx.set_seq2(hq[0])
+        ref0 = ctx.search(0, total)
+        one_result = psa.Result()
+        single_c_call_us = wall_us(lambda: psa.lib.psa_search(ctx._h, 0, total, C.byref(one_result)), 40, warm=5)
+        ref_batch = ctx.search_batch(hq)
+        ref_hi, ref_lo = ctx.search_batch_minmax(hq[:64])
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
 
     def run_group(devices, exchange, label):
         out = {"devices": list(devices), "exchange": label}
@@ -331,8 +335,11 @@ def group_leg_main(args):
                 issue.append(g.last_timing()[0])
             blocking = wall_us(one, 24)
             issue = sorted(issue[3:])
+            best, records = psa.Result(), (psa.Result * len(devices))()
+            c_call = wall_us(lambda: psa.lib.psa_search_sharded(g._h, 0, total, C.byref(best), records), 40, warm=5)
             out["sharded_search"] = {
-                "blocking_us": blocking, "host_issue_us": issue[len(issue) // 2], "host_issue_us_max": issue[-1],
+                "blocking_us": blocking, "c_call_us": c_call, "single_context_c_call_us": single_c_call_us,
+                "host_issue_us": issue[len(issue) // 2], "host_issue_us_max": issue[-1],
                 "pairs_per_s": total * m / (blocking * 1e-6), "equals_single_context": bool(ok),
                 "shard_offsets": [psa.shard_range(total, len(devices), r) for r in (0, len(devices) - 1)]}
             batches = {}
@@ -365,6 +372,8 @@ def group_leg_main(args):
     print(json.dumps({"mode": mode, "visible_devices": have, "groups": legs, "ok": all(l["ok"] for l in legs),
                       "note": "psa_search_sharded / psa_search_batch_sharded through psa.Group (ctypes): configs[3] = one blocking "
                               "1M x 10k MAX search, offsets sharded; configs[4] = 64 / 256 queries dealt to the devices.  "
+                              "c_call_us / single_context_c_call_us = the bare C entry points (psa_search_sharded / psa_search of one context), same "
+                              "process, buffers allocated beforehand: their difference is what the group and its exchange add; "
                               "host_issue_us = from the call's entry until the LAST device's launch had been enqueued (persistent "
                               "launcher thread per device; one thread issuing 8 launches in turn took ~40 us).  N > 1 with RCCL has "
                               "only ever run where this object says exchange = RCCL with more than one device"}), flush=True)

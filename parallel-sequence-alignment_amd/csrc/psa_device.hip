@@ -434,7 +434,8 @@ struct SearchSlot {
     unsigned long long* d_partial = nullptr;   size_t partial_cap = 0;   // [nchunks][span_pad] counts of a multi-chunk search
     int*                d_arrivals = nullptr;  int arrivals_cap = 0;     // [ntiles], zero between searches
     // shared combine of a fused multi-chunk search: per tile a "ready" tag, per (tile, chunk) a "claimed" tag (launch numbers)
-    int*                d_share = nullptr;
+    unsigned long long* d_share = nullptr;
+    unsigned long long  share_launches = 0;      // sharing launches on this slot so far: the next one's tag
     Scalars*            d_scal = nullptr;
     unsigned long long* d_best_split = nullptr;   // kBestSplit words of the running bound, a cache line each (zero between searches)
     int*                d_cand = nullptr;
@@ -454,8 +455,8 @@ struct psa_context {
     hipStream_t twin = nullptr;        // owned: every other count kernel of a pooled batch (kernels overlap at their edges)
     int batch_streams = 1;             // count launches of a batch on one stream (2: alternate between two, psa_set_batch_streams)
     int batch_rescore_grid = 8;        // re-score workgroups per query inside a batch (the CUs are busy counting)
-    int granted16 = 0;                 // dynamic-LDS grant of the count kernel on this context's device
-    bool granted16_raw = false;
+    // dynamic-LDS grants of the count kernel's instances on this context's device: [raw][chunked]
+    bool granted16[2][2] = {{false, false}, {false, false}};
     // Shares of a SIMD's four waves in the single-search count kernel, by age (oldest first), in permille.  The hardware
     // issues the oldest wave of a SIMD first: with equal shares it finished 25 us before the youngest and the SIMD ended on
     // one wave that cannot fill its issue slots.  Round 3, first form (every wave converted its own counts, the older ones
@@ -1141,8 +1142,15 @@ bool plan_filter(int first, int last, int m, FilterPlan* best, int max_chunks)
             const long long rounds_cu = (blocks + 255) / 256;        // waves of co-resident workgroups
             // Microseconds, fitted on MI355X (tools/plan_sweep.py, gpurun_out/plan_sweep_*.txt): the youngest wave of a
             // workgroup needs ~0.17 us per char of a class, a workgroup ~8 us around its main loop, the launch ~11 us;
-            // the chunk workgroups of a tile meet through memory (write-through stores, arrival counter, the last
-            // arriver reads the others' counts).
+            // the chunk workgroups of a tile meet through memory (write-through stores, arrival counter, the others'
+            // counts read back).  The chunk term is round 4's fit (the tile's last arriver read the other chunks' counts in
+            // a rolled loop, a memory round trip each, and selected alone).  Round 5 (loads issued ahead, 16-byte publish
+            // stores, plans that fit the CUs share the tile's combine: psa_count_kernel) took 2-2.5 us off every such plan
+            // without changing their order — gpurun_out/plan_sweep_r5.txt, kernel us for 1M x 10k, chunks 3 / 4 / 5 / 10:
+            // 123,750 offsets 52.4 / 49.0 / 44.0 / 62.7 (two waves of workgroups), 247,500: 55.8 / 54.2 / 65.5 / 85.4,
+            // 8,000: 50.9 / 47.0 / 40.9 / 41.2 — so the fit stays: it ranks the plans right, its absolute value is high
+            // by those 2 us.  A chunked search of TWO tiles takes 40.7 us: launch, planes, counter sums, hand-off,
+            // selection and the search's tail (12 us) are what a shard cannot shed.
             const double cost = (double)rounds_cu * (0.17 * class_chars + 8.0) + 11.0 +
                                 (nchunks > 1 ? 2.3 + 1.7 * nchunks + 0.02 * (double)blocks : 0.0);
             if (!found || cost < best_cost) {
@@ -1359,17 +1367,19 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.tile_arrivals = s.d_arrivals;
     a.share = 0;
     a.share_spins = c->share_spins;
+    a.share_tag = 0ull;
     a.tile_ready = a.slice_claim = nullptr;
     a.done_target = p.ntiles;
     if (fused && inline_select && c->share_combine && p.nchunks > 1 && p.nchunks <= psa::kShareMaxChunks && p.ntiles <= psa::kShareMaxTiles &&
         (long long)p.ntiles * p.nchunks <= c->cus) {
         // (every chunk workgroup of every tile is resident at once: they share the tiles' combine + selection)
-        constexpr size_t kShareInts = (size_t)psa::kShareMaxTiles * (1 + psa::kShareMaxChunks);
+        constexpr size_t kShareWords = (size_t)psa::kShareMaxTiles * (1 + psa::kShareMaxChunks);
         if (!s.d_share) {
-            PSA_TRY(dev_alloc(&s.d_share, kShareInts));
-            PSA_HIP(hipMemsetAsync(s.d_share, 0, sizeof(int) * kShareInts, stream));     // (launch numbers start at 1)
+            PSA_TRY(dev_alloc(&s.d_share, kShareWords));
+            PSA_HIP(hipMemsetAsync(s.d_share, 0, sizeof(unsigned long long) * kShareWords, stream));     // (launch numbers start at 1)
         }
         a.share = 1;
+        a.share_tag = ++s.share_launches;
         a.tile_ready = s.d_share;
         a.slice_claim = s.d_share + psa::kShareMaxTiles;
         a.done_target = p.ntiles * p.nchunks;
@@ -1444,26 +1454,29 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
             a.raw_arrivals = c->d_raw_arrivals;
             a.raw_base = c->raw_arrived;
         }
-        if (!c->granted16_raw) {
-            PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16, true>),
+        const bool chunked = p.nchunks > 1 || !inline_select;
+        auto kernel = chunked ? &psa::psa_count_kernel<16, true, true> : &psa::psa_count_kernel<16, true, false>;
+        if (!c->granted16[1][chunked]) {
+            PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, psa::kCountLdsBytes));   // (+ 2.3 KB static)
-            c->granted16_raw = true;
+            c->granted16[1][chunked] = true;
         }
-        hipLaunchKernelGGL((psa::psa_count_kernel<16, true>), dim3(p.ntiles + a.raw_converters, p.nchunks), dim3(16 * 64), p.lds_bytes,
-                           stream, a);
+        hipLaunchKernelGGL(kernel, dim3(p.ntiles + a.raw_converters, p.nchunks), dim3(16 * 64), p.lds_bytes, stream, a);
         c->last_kernel = "psa_count_kernel<16, raw>";
         PSA_HIP(hipGetLastError());
         c->raw_arrived += (unsigned)a.raw_converters;           // every converter arrives, however the search ends
         return PSA_OK;
     }
-    // dynamic LDS above 64 KB has to be granted per kernel (and device: the flags live in the context)
-    if (p.lds_bytes > c->granted16) {
-        PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&psa::psa_count_kernel<16>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
-        c->granted16 = kLdsLimit;
+    // dynamic LDS above 64 KB has to be granted per kernel instance (and device: the flags live in the context).
+    // One char chunk per tile, selected inline (every full-size single search): the instance without the chunk hand-off.
+    const bool chunked = p.nchunks > 1 || !inline_select;
+    auto kernel = chunked ? &psa::psa_count_kernel<16, false, true> : &psa::psa_count_kernel<16, false, false>;
+    if (!c->granted16[0][chunked]) {
+        PSA_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsLimit));
+        c->granted16[0][chunked] = true;
     }
     PSA_STRACE(2);
-    hipLaunchKernelGGL(psa::psa_count_kernel<16>, grid, dim3(16 * 64), p.lds_bytes, stream, a);
+    hipLaunchKernelGGL(kernel, grid, dim3(16 * 64), p.lds_bytes, stream, a);
     c->last_kernel = "psa_count_kernel<16>";
     PSA_HIP(hipGetLastError());
     PSA_STRACE(3);
@@ -3137,6 +3150,12 @@ psa_status psa_group_create_ex(const int* devices, int ndev, int exchange, psa_g
             psa_context* c = nullptr;
             PSA_TRY(psa_create(devices[i], nullptr, &c));
             g->ctx.push_back(c);
+            // a GPU listed several times (host exchange: an N-way split rehearsed on fewer GPUs) runs several shards at
+            // once: the chunk workgroups of a tile are not resident together there, and waiting for each other only holds
+            // CUs the others need (8 contexts on one GPU: 260 us per call instead of 175) — the last arriver does the tile
+            int listed = 0;
+            for (int k = 0; k < ndev; ++k) listed += devices[k] == devices[i];
+            if (listed > 1) c->share_combine = false;
         }
         if (exchange == PSA_EXCHANGE_RCCL) {
             g->comm.assign((size_t)ndev, nullptr);

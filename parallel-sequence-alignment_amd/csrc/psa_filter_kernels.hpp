@@ -2149,7 +2149,8 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
 // ---- count kernel --------------------------------------------------------------
 constexpr int kShareMaxChunks = 32;       // chunk workgroups of a tile that may share its combine (one claim word each)
 constexpr int kShareMaxTiles = 256;       // ... of at most this many tiles (tiles x chunks <= the CUs)
-constexpr int kShareSpins = 16;           // polls (~2 us apart: a memory round trip + a short sleep) of a tile's "ready" tag before a chunk workgroup leaves
+constexpr unsigned long long kShareLeft = 1ull << 63;
+constexpr int kShareSpins = 16;           // polls (a memory round trip each, ~0.7 us) of a tile's "ready" tag before a chunk workgroup leaves
 struct CountArgs {
     const unsigned char* s1;        // Seq1 symbol codes, padded with kCodePad (32 per slot)
     const unsigned*      classes;   // Seq2 symbols as LDS row offsets (code << kRowShift) in class order (class_index)
@@ -2162,8 +2163,9 @@ struct CountArgs {
     // shared combine (fused single searches whose tiles x chunks fit the CUs): every chunk workgroup takes a slice of its tile
     int  share;           // 0: the tile's last arriver combines and selects alone
     int  share_spins;     // polls of the tile's "ready" tag before a workgroup leaves (debug library: 0 = leave at once)
-    int* tile_ready;      // [ntiles] the number of the launch whose chunk counts of this tile are complete
-    int* slice_claim;     // [ntiles][kShareMaxChunks] the number of the launch in which this slice was taken
+    unsigned long long  share_tag;    // this launch's number among the slot's sharing launches (64 bits: never repeats)
+    unsigned long long* tile_ready;   // [ntiles] the tag of the launch whose chunk counts of this tile are complete
+    unsigned long long* slice_claim;  // [ntiles][kShareMaxChunks] tag | kShareLeft: the slice's owner left; tag: it has a taker
     int  done_target;     // arrivals on tail.done that end the search: tiles (x chunks when sharing)
     // single-chunk searches finish here: score bounds per offset, running best pessimistic
     // bound (atomic max), candidates = offsets whose optimistic bound reaches it.  The counts do
@@ -2218,7 +2220,9 @@ struct CountArgs {
 #define PSA_CPHASE(k) do { } while (0)
 #endif
 
-template <int WAVES, bool RAW = false>
+// CHUNKED = false: the launch has ONE char chunk per tile and selects inline (grid.y == 1: every full-size single search) —
+// the chunk hand-off, the shared combine and their loops are compiled out of that instance: its tail is straight-line code.
+template <int WAVES, bool RAW = false, bool CHUNKED = true>
 __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) uint2 lds[];   // [kMaskRows][lds_slots] planes, the count cells; the tail's buffers
@@ -2404,17 +2408,24 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     __shared__ unsigned long long s_best[2][WAVES + 1];
     __shared__ int s_flag;
     __shared__ int s_last_tile;
-    const int nchunks = (int)gridDim.y;
-    const int tag = a.tail.seq;                         // this launch's number: what "ready" and "claimed" words must show
+    const int nchunks = CHUNKED ? (int)gridDim.y : 1;
+    const unsigned long long tag = a.share_tag;         // this launch's number: what "ready" and "claimed" words must show
     bool last_chunk = true;
-    if (!a.inline_select || nchunks > 1) {
+    if (CHUNKED && (!a.inline_select || nchunks > 1)) {
         // ---- several char chunks per tile (or psa_debug_counts): every chunk workgroup publishes its counts
         unsigned long long* dst = a.partial + (size_t)blockIdx.y * a.span_pad + (size_t)tile_x * kTile + o_local;
         // write-through (sc1) stores: they leave the XCD's L2 at once, so the hand-off below needs no L2 write-back
+        // (16 bytes each: half the requests of 8-byte atomic stores)
+        static_assert(kPer == 4, "two 16-byte stores per thread");
+        unsigned long long pk[kPer];
 #pragma unroll
         for (int e = 0; e < kPer; ++e)
-            __hip_atomic_store(dst + e, (unsigned long long)n[0][e] | ((unsigned long long)n[1][e] << 21) |
-                                            ((unsigned long long)n[2][e] << 42), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pk[e] = (unsigned long long)n[0][e] | ((unsigned long long)n[1][e] << 21) | ((unsigned long long)n[2][e] << 42);
+        typedef unsigned v4u __attribute__((ext_vector_type(4)));
+        const v4u q0 = {(unsigned)pk[0], (unsigned)(pk[0] >> 32), (unsigned)pk[1], (unsigned)(pk[1] >> 32)};
+        const v4u q1 = {(unsigned)pk[2], (unsigned)(pk[2] >> 32), (unsigned)pk[3], (unsigned)(pk[3] >> 32)};
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1"
+                     : : "v"(dst), "v"(q0), "v"(q1) : "memory");
         if (!a.inline_select) return;
         // The chunk workgroups of a tile meet through memory; they may sit on different XCDs (separate L2s).  Producer:
         // every byte is stored sc1, every storing wave drains its stores (vmcnt(0)), the workgroup barrier, then ONE
@@ -2443,19 +2454,30 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
             // Without sharing the tile's last chunk workgroup to arrive adds the others' counts to its own and goes on
             // alone (plans of more workgroups than CUs, batches: the others have no reason to be resident still).
             if (!a.share) return;
-            // sharing: wait — with a bound — for the tile's "ready" tag
+            // sharing: wait — with a bound — for the tile's "ready" tag.  A workgroup that has waited in vain marks its slice
+            // "left" and looks once more (the tag may have come in between: then it takes the slice back unless the tile's
+            // last arriver has taken it already).
             __syncthreads();
             if (tid == 0) {
-                int seen = 0;
+                int go = 0;
                 for (int spins = 0; spins < a.share_spins; ++spins) {
-                    if (__hip_atomic_load(a.tile_ready + tile_x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) { seen = 1; break; }
-                    __builtin_amdgcn_s_sleep(16);
+                    if (__hip_atomic_load(a.tile_ready + tile_x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) { go = 1; break; }
+                    __builtin_amdgcn_s_sleep(1);
                 }
-                if (seen) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                s_flag = seen;
+                if (!go) {
+                    unsigned long long* const mine = a.slice_claim + (size_t)tile_x * kShareMaxChunks + blockIdx.y;
+                    (void)__hip_atomic_exchange(mine, tag | kShareLeft, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the mark is in memory before the second look
+                    if (__hip_atomic_load(a.tile_ready + tile_x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tag) {
+                        unsigned long long expect = tag | kShareLeft;
+                        go = __hip_atomic_compare_exchange_strong(mine, &expect, tag, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                    }
+                }
+                if (go) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                s_flag = go;
             }
             __syncthreads();
-            if (!__builtin_amdgcn_readfirstlane(s_flag)) return;     // gave up: the tile's last arriver takes this slice
+            if (!__builtin_amdgcn_readfirstlane(s_flag)) return;     // left: the tile's last arriver takes this slice
         }
     }
     // ---- SHARED COMBINE (a fused single search whose tiles x chunks fit the GPU's CUs: an offset shard).  One workgroup
@@ -2464,15 +2486,17 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
     // tile's other C - 1 CUs have gone idle.  Instead every chunk workgroup waits for the tile's "ready" tag (the last
     // arriver's store) and takes the C-th part of the tile's offsets — slice c = blockIdx.y: its own counts from LDS, the
     // others' from memory, bounds, selection, and its own arrival on the search's counter (done_target = tiles x chunks).
-    // NOBODY WAITS WITHOUT A BOUND: a workgroup that does not see the tag within share_spins polls leaves (its peers are
-    // not resident: the GPU is shared).  Every slice has a "claimed" word (atomic exchange with the launch's tag: exactly
-    // one taker); the tile's last arriver, which waits for nobody, takes its own slice and then every slice it finds
-    // unclaimed — so each slice is processed exactly once whoever left, and no word needs zeroing between launches.
+    // NOBODY WAITS WITHOUT A BOUND: a workgroup that does not see the tag within share_spins polls marks its slice "left"
+    // and goes (its peers are not resident: the GPU is shared).  The tile's last arriver, which waits for nobody, takes its
+    // own slice and then every slice it finds marked "left" (compare-and-swap left -> taken) — so each slice is processed
+    // exactly once: by its owner if the owner saw the tag (no atomic on that path) or won its slice back, else by the last
+    // arriver, whose sweep comes after the tag is in memory (an owner that marks "left" later sees the tag at its second
+    // look).  Tags are 64-bit launch numbers: no word needs zeroing between launches.
     // Without sharing there is one "slice": the whole tile, this workgroup's.
-    const bool sharing = nchunks > 1 && a.share != 0;
+    const bool sharing = CHUNKED && nchunks > 1 && a.share != 0;
     const int nslices = sharing ? nchunks : 1;
     const int groups = (sharing ? kTileStride : kTile) / kPer;           // groups of kPer offsets that are dealt out
-    int* const claim = a.slice_claim + (size_t)tile_x * kShareMaxChunks;
+    unsigned long long* const claim = a.slice_claim + (size_t)tile_x * kShareMaxChunks;
     bool finish = false;
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
@@ -2480,23 +2504,27 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
         if (!sharing) {
             if (pass == 1) break;
         } else {
-            if (pass == 1 && !last_chunk) break;
-            // its own slice; the last arriver then asks for all the others.  One lane per wanted slice exchanges its
-            // "claimed" word, all at once
-            const unsigned long long todo = pass == 0 ? 1ull << blockIdx.y : ((1ull << nchunks) - 1ull) & ~(1ull << blockIdx.y);
-            __syncthreads();
-            if (wave == 0) {
-                const bool want = lane < nchunks && ((todo >> lane) & 1ull);
-                int old = tag;
-                if (want) old = __hip_atomic_exchange(claim + lane, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned long long got = __ballot(want && old != tag);
-                if (lane == 0) s_best[0][WAVES] = got;
+            if (pass == 0) {
+                mine = 1ull << blockIdx.y;                 // its own slice
+            } else {
+                if (!last_chunk) break;
+                // the tile's last arriver: every other slice whose owner has left — one lane per slice, all at once
+                __syncthreads();
+                if (wave == 0) {
+                    bool got = false;
+                    if (lane < nchunks && lane != (int)blockIdx.y) {
+                        unsigned long long expect = tag | kShareLeft;
+                        got = __hip_atomic_compare_exchange_strong(claim + lane, &expect, tag, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const unsigned long long all = __ballot(got);
+                    if (lane == 0) s_best[0][WAVES] = all;
+                }
+                __syncthreads();
+                const unsigned long long all = s_best[0][WAVES];
+                mine = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)all) |
+                       ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(all >> 32)) << 32);
+                __syncthreads();
             }
-            __syncthreads();
-            const unsigned long long got = s_best[0][WAVES];
-            mine = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)got) |
-                   ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(got >> 32)) << 32);
-            __syncthreads();
         }
 #pragma unroll 1
         while (mine) {
@@ -2504,9 +2532,11 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
             mine &= mine - 1ull;
             const int g0 = slice * groups / nslices, g1 = (slice + 1) * groups / nslices;
             const bool active = tid < g1 - g0;
-            o_local = (active ? g0 + tid : g0) * kPer;
-            read_cells<kPer>(n, cells, kTileWords, o_local);
-            if (nchunks > 1) {
+            if constexpr (CHUNKED) {
+                o_local = (active ? g0 + tid : g0) * kPer;
+                read_cells<kPer>(n, cells, kTileWords, o_local);
+            }
+            if (CHUNKED && nchunks > 1) {
                 // the other chunks' counts of this thread's kPer offsets.  The loads of kCombineAhead chunks are all issued
                 // before the first is used (a slot beyond the last chunk reads this workgroup's own counts and is masked
                 // out: straight-line code, no branch between the loads).  A rolled loop waited one memory round trip per

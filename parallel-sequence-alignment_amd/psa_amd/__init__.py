@@ -109,8 +109,11 @@ def _load() -> C.CDLL:
         lib.psa_debug_counts.argtypes = [vp, i, i, vp, vp, vp]
         lib.psa_debug_rescore.argtypes = [vp, vp, i, vp]
     lib.psa_fallback_count.argtypes = [vp]
-    lib.psa_scratch_fallback_count.argtypes = [vp]
-    lib.psa_scratch_shrink_count.argtypes = [vp]
+    # (symbols newer than round 4 are bound when present: tools/shard_ab.sh loads older builds of the library for A/B runs;
+    # __graft_entry__.build() and the tests check EXPORTED_SYMBOLS against the in-tree build)
+    if hasattr(lib, "psa_scratch_fallback_count"):
+        lib.psa_scratch_fallback_count.argtypes = [vp]
+        lib.psa_scratch_shrink_count.argtypes = [vp]
     lib.psa_reselect_count.argtypes = [vp]
     lib.psa_duo_retry_count.argtypes = [vp]
     lib.psa_unfused_count.argtypes = [vp]
@@ -125,7 +128,8 @@ def _load() -> C.CDLL:
     lib.psa_search_sharded.argtypes = [vp, i, i, C.POINTER(Result), C.POINTER(Result)]
     lib.psa_search_batch_sharded.argtypes = [vp, C.c_char_p, i, i, C.c_size_t, i, i, C.POINTER(Result), C.POINTER(Result)]
     lib.psa_group_last_timing.argtypes = [vp, dp, dp]
-    lib.psa_group_set_timeout.argtypes = [vp, C.c_double]
+    if hasattr(lib, "psa_group_set_timeout"):
+        lib.psa_group_set_timeout.argtypes = [vp, C.c_double]
     lib.psa_fold.argtypes = [C.POINTER(Result), i, i, C.POINTER(Result)]
     lib.psa_shard_range.argtypes = [i, i, i, C.POINTER(i), C.POINTER(i)]
     lib.psa_shard_range.restype = None
