@@ -73,3 +73,30 @@ def test_chunked_filter_engine_beats_the_sequential_engine(psa, n, m):
             c.search()
             took.append(c.last_timing(0)[0])
     assert took[0] * 3 < took[1], took
+
+
+def test_one_shot_search_of_a_small_range_does_not_pay_for_a_long_seq1(psa):
+    """psa_search_device over a sub-range has its converter workgroups validate the Seq1 bytes outside the tiles'
+    windows while the tiles wait; with a fixed 16 converters a 100,000-offset search under a 2^27-character Seq1 took 359 us
+    (2^30: 3.3 ms) against 40 us under 2^20.  The converters now scale with those bytes (tools/subrange_oneshot.py: 68 us,
+    2^30: 300 us).  Threshold: 200 us at 2^27; the answer equals the two-launch path's."""
+    import time
+    import torch
+    n, m, span = 1 << 27, 1000, 100_000
+    t1 = torch.randint(65, 91, (n,), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    t2 = torch.randint(65, 91, (m,), dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(6))
+    torch.cuda.synchronize()
+    key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
+    with psa.Context(0) as c:
+        c.set_weights(W_README, True)
+        lo = n // 2
+        took = []
+        for k in range(12):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            got = c.search_device(t1.data_ptr(), n, t2.data_ptr(), m, lo, lo + span)
+            took.append(time.perf_counter() - t0)
+        assert c.raw_retry_count() == 0
+        c.set_sequences_device(t1.data_ptr(), n, t2.data_ptr(), m)
+        assert key(c.search(lo, lo + span)) == key(got)
+    assert sorted(took[2:])[5] < 200e-6, took

@@ -37,6 +37,8 @@ with psa.Context(0) as cf, psa.Context(0) as cs, psa.Context(0) as ca:      # ca
         total = n - m + 1
         first = int(rng.integers(0, max(1, total // 2)))
         last = int(rng.integers(first + 1, total + 1))
+        if os.environ.get("SOAK_SHARD") == "1":            # offset shards: few tiles, several char chunks (the shared combine)
+            last = min(total, first + int(rng.choice([1, 37, 4064, 4065, 30_000, 123_750, 247_500, 400_000])))
         for c in (cf, cs, ca):
             c.set_weights(w, True)
             c.set_seq1(s1)
