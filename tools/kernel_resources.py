@@ -29,8 +29,11 @@ for blk in re.split(r"remark: [^\n]*Function Name: ", usage)[1:]:
                            f(r"ScratchSize \[bytes/lane\]"), f(r"Occupancy \[waves/SIMD\]"), f(r"LDS Size \[bytes/block\]")]))
 out.append("")
 out.append("# main loops (basic blocks with > 400 v_bitop3_b32): VALU instructions, and spill / scratch code inside them")
-for kern in ("_ZN3psa16psa_count_kernelILi16ELb0EEEvNS_9CountArgsE", "_ZN3psa16psa_count_kernelILi16ELb1EEEvNS_9CountArgsE",
-             "_ZN3psa20psa_count_duo_kernelENS_7DuoArgsE"):
+COUNT = "_ZN3psa16psa_count_kernelILi16ELb%dELb%dEEEvNS_9CountArgsE"        # <16, RAW, CHUNKED>
+NAMES = {COUNT % (0, 0): "psa_count_kernel<16> (one chunk per tile)", COUNT % (0, 1): "psa_count_kernel<16> (chunked)",
+         COUNT % (1, 0): "psa_count_kernel<16, raw> (one chunk per tile)", COUNT % (1, 1): "psa_count_kernel<16, raw> (chunked)",
+         "_ZN3psa20psa_count_duo_kernelENS_7DuoArgsE": "psa_count_duo_kernel"}
+for kern in NAMES:
     i = asm.index(kern + ":")
     body = asm[i:asm.index(".Lfunc_end", i)]
     blocks, cur = [], ("entry", [])
@@ -44,7 +47,7 @@ for kern in ("_ZN3psa16psa_count_kernelILi16ELb0EEEvNS_9CountArgsE", "_ZN3psa16p
     blocks.append(cur)
     total_lane = sum("v_readlane" in l or "v_writelane" in l for _, b in blocks for l in b)
     total_scratch = sum("scratch_" in l for _, b in blocks for l in b)
-    short = ("psa_count_kernel<16, raw>" if "ELb1" in kern else "psa_count_kernel<16>") if "count_kernelILi16" in kern else "psa_count_duo_kernel" 
+    short = NAMES[kern]
     for name, b in blocks:
         nb = sum("v_bitop3" in l for l in b)
         if nb > 400:
