@@ -777,6 +777,9 @@ def main():
                 ctx.set_sequences_device(p1, n, p2, m)
         shard_emulation = {
             "blocking_search_us_per_rank": per_search,
+            # slices of shared combines that a tile's last workgroup had to take over (their own workgroups waited in vain):
+            # 0 unless something else was running on this GPU during the probe — the 1/2, 1/4, 1/8 figures are then too high
+            "slices_taken_over": ctx.share_sweep_count() if hasattr(ctx, "share_sweep_count") else None,
             "blocking_search_speedup_at_8": per_search["1"] / per_search["8"],
             "batch_of_%d_ms_per_rank" % nb: per_batch,
             "batch_speedup_at_8": (per_batch["1"] / per_batch["8"]) if per_batch else None,

@@ -212,6 +212,11 @@ int psa_fallback_count(psa_context* ctx);
  * search run in pieces or sequentially, not fail).  A blocking psa_search over the cap runs in pieces and is not counted. */
 int psa_scratch_fallback_count(psa_context* ctx);
 int psa_scratch_shrink_count(psa_context* ctx);
+/* Offset shards (a fused search of few tiles under several char chunks) let every chunk workgroup of a tile take a slice
+ * of the tile's combine + selection.  A workgroup whose peers do not show up in time (they are not resident: the GPU is
+ * shared with other work) leaves, and the tile's last workgroup takes its slice over: this counts those slices — 0 on a
+ * GPU the context has to itself.  Synchronises the context's stream; -1 on a device error. */
+long long psa_share_sweep_count(psa_context* ctx);
 /* Filter searches of this context whose candidate selection ran twice: candidates are picked
  * against a running bound while the tiles finish; when that overflows the list, the selection
  * is repeated against the final bound (only a second overflow goes to the sequential engine). */

@@ -1368,20 +1368,29 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.share = 0;
     a.share_spins = c->share_spins;
     a.share_tag = 0ull;
-    a.tile_ready = a.slice_claim = nullptr;
+    a.tile_ready = a.slice_claim = a.share_swept = nullptr;
     a.done_target = p.ntiles;
     if (fused && inline_select && c->share_combine && p.nchunks > 1 && p.nchunks <= psa::kShareMaxChunks && p.ntiles <= psa::kShareMaxTiles &&
         (long long)p.ntiles * p.nchunks <= c->cus) {
         // (every chunk workgroup of every tile is resident at once: they share the tiles' combine + selection)
-        constexpr size_t kShareWords = (size_t)psa::kShareMaxTiles * (1 + psa::kShareMaxChunks);
+        constexpr size_t kShareWords = (size_t)psa::kShareMaxTiles * (1 + psa::kShareMaxChunks) + 1;     // (+ the sweep counter)
         if (!s.d_share) {
             PSA_TRY(dev_alloc(&s.d_share, kShareWords));
             PSA_HIP(hipMemsetAsync(s.d_share, 0, sizeof(unsigned long long) * kShareWords, stream));     // (launch numbers start at 1)
         }
         a.share = 1;
         a.share_tag = ++s.share_launches;
+        if (a.share_spins > 0) {
+            // the last chunk of a plan may be shorter than the others (10 rounds as 3 + 3 + 3 + 1): its workgroups arrive that
+            // much earlier and must not give up on the others for it — 0.17 us per char of a class (the planner's figure),
+            // a poll every ~0.75 us
+            const int rounds_total = ((s.m + psa::kClasses - 1) / psa::kClasses + psa::kUnroll - 1) / psa::kUnroll;
+            const int last_chars = (rounds_total - (p.nchunks - 1) * (p.class_chars / psa::kUnroll)) * psa::kUnroll;
+            if (last_chars > 0 && last_chars < p.class_chars) a.share_spins += (int)(0.17 * (p.class_chars - last_chars) / 0.75) + 1;
+        }
         a.tile_ready = s.d_share;
         a.slice_claim = s.d_share + psa::kShareMaxTiles;
+        a.share_swept = s.d_share + kShareWords - 1;
         a.done_target = p.ntiles * p.nchunks;
     }
     a.inline_select = inline_select ? 1 : 0;
@@ -1944,6 +1953,20 @@ psa_status psa_create(int device, void* stream, psa_context** out)
 // Searches / batches of this context that the sequential engine answered because the filter engine's per-chunk counts
 // would have exceeded the context's cap (16 GB, half of the device's free memory at psa_create, less after a failed
 // allocation), and how often a failed allocation lowered that cap.
+// Slices of shared combines (offset shards: psa_count_kernel) that a tile's last arriver had to take over because their
+// own workgroup had waited in vain — 0 on a GPU this context has to itself; a shared GPU makes it grow (and such searches
+// slower: the tile's workgroups were not resident together).  Reads one word from the device (synchronises the stream).
+long long psa_share_sweep_count(psa_context* c)
+{
+    if (!c || !c->slot[0].d_share) return 0;
+    DeviceScope device_scope;
+    if (hipSetDevice(c->device) != hipSuccess) return -1;
+    unsigned long long v = 0;
+    constexpr size_t last = (size_t)psa::kShareMaxTiles * (1 + psa::kShareMaxChunks);
+    if (hipStreamSynchronize(c->stream) != hipSuccess ||
+        hipMemcpy(&v, c->slot[0].d_share + last, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return (long long)v;
+}
 int psa_scratch_fallback_count(psa_context* c) { return c ? c->scratch_fallbacks : 0; }
 int psa_scratch_shrink_count(psa_context* c) { return c ? c->scratch_shrinks : 0; }
 

@@ -2166,6 +2166,7 @@ struct CountArgs {
     unsigned long long  share_tag;    // this launch's number among the slot's sharing launches (64 bits: never repeats)
     unsigned long long* tile_ready;   // [ntiles] the tag of the launch whose chunk counts of this tile are complete
     unsigned long long* slice_claim;  // [ntiles][kShareMaxChunks] tag | kShareLeft: the slice's owner left; tag: it has a taker
+    unsigned long long* share_swept;  // health counter: slices the tiles' last arrivers had to take over (psa_share_sweep_count)
     int  done_target;     // arrivals on tail.done that end the search: tiles (x chunks when sharing)
     // single-chunk searches finish here: score bounds per offset, running best pessimistic
     // bound (atomic max), candidates = offsets whose optimistic bound reaches it.  The counts do
@@ -2526,16 +2527,26 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
                 __syncthreads();
             }
         }
-#pragma unroll 1
-        while (mine) {
-            const int slice = __builtin_ctzll(mine);
-            mine &= mine - 1ull;
-            const int g0 = slice * groups / nslices, g1 = (slice + 1) * groups / nslices;
-            const bool active = tid < g1 - g0;
-            if constexpr (CHUNKED) {
-                o_local = (active ? g0 + tid : g0) * kPer;
-                read_cells<kPer>(n, cells, kTileWords, o_local);
+        if (mine == 0ull) break;                         // (pass 1: every other owner took its slice itself)
+        {
+            // pass 0: ONE slice — this workgroup's (without sharing: the whole tile) — dealt to threads 0 .. its size;
+            // pass 1 (the tile's last arriver): ALL the slices it swept in one go, every thread at its place in the tile
+            // (all owners leaving is how it goes when the GPU is shared: five slices one after the other cost 40 us)
+            const int taken = __builtin_popcountll(mine);
+            bool active;
+            if (pass == 0) {
+                const int slice = __builtin_ctzll(mine);
+                const int g0 = slice * groups / nslices, g1 = (slice + 1) * groups / nslices;
+                active = tid < g1 - g0;
+                if constexpr (CHUNKED) o_local = (active ? g0 + tid : g0) * kPer;
+            } else {
+                int slice = tid * nslices / groups;                         // the slice whose [g0, g1) holds group `tid`
+                if (slice + 1 < nslices && tid >= (slice + 1) * groups / nslices) ++slice;
+                active = tid < groups && ((mine >> slice) & 1ull) != 0ull;
+                o_local = tid * kPer;
+                if (tid == 0) __hip_atomic_fetch_add(a.share_swept, (unsigned long long)taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if constexpr (CHUNKED) read_cells<kPer>(n, cells, kTileWords, o_local);
             if (CHUNKED && nchunks > 1) {
                 // the other chunks' counts of this thread's kPer offsets.  The loads of kCombineAhead chunks are all issued
                 // before the first is used (a slot beyond the last chunk reads this workgroup's own counts and is masked
@@ -2612,9 +2623,12 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
 #ifdef PSA_EXPERIMENT
                 if (a.select_frozen) need = -1.7976931348623157e308;    // every real offset is a candidate (not the -inf of the others)
 #endif
+                // (a SLICE may lie wholly outside the searched range — the last tile's end — and run before any bound exists:
+                // its key and `need` are then -inf, and "-inf >= -inf" must not make candidates of offsets that do not exist:
+                // 4,096 of them overflowed the list and sent the search through a re-selection launch, now and then)
 #pragma unroll
                 for (int e = 0; e < kPer; ++e)
-                    if (up[mode][e] >= need) {
+                    if (up[mode][e] >= need && up[mode][e] != -INFINITY) {
                         const int slot = atomicAdd(sel.cand_count, 1);
                         if (slot < a.cap) {
                             store_agent(sel.cand + slot, a.first + tile_x * kTileStride + o_local + e - a.lead);
@@ -2635,8 +2649,8 @@ __global__ __launch_bounds__(WAVES * 64, 4) void psa_count_kernel(CountArgs a)
 #ifdef PSA_PHASE_TIMING
                 if (blockIdx.x < 244) g_phase_ts[700 + blockIdx.x][2] = wall_clock64();
 #endif
-                const int arrived = __hip_atomic_fetch_add(a.tail.done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last_tile = arrived == a.done_target - 1;
+                const int arrived = __hip_atomic_fetch_add(a.tail.done, taken, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last_tile = arrived + taken == a.done_target;
 #ifdef PSA_PHASE_TIMING
                 if (blockIdx.x < 244) { g_phase_ts[700 + blockIdx.x][3] = wall_clock64(); g_phase_ts[700 + blockIdx.x][4] = (unsigned long long)arrived; }
 #endif

@@ -1711,6 +1711,10 @@ def test_offset_shards_share_the_tiles_combine(psa, psa_debug, monkeypatch):
                 for c in (cp, sweep):
                     c.set_sequences(s1, s2)
         assert cp.fallback_count() == 0 and sweep.fallback_count() == 0 and alone.fallback_count() == 0
+        # who did the slices: with PSA_SHARE_SPINS=0 everybody leaves and the last arrivers take every other slice over (in
+        # one pass per tile); PSA_SHARE=0 has no slices.  (How rarely a PRODUCT workgroup waits in vain on a quiet GPU is a
+        # timing matter: tests/test_zz_bench_contract.py.)
+        assert sweep.share_sweep_count() > 1000 and alone.share_sweep_count() == 0, (sweep.share_sweep_count(), alone.share_sweep_count())
         # ties: every 4th offset of an ACGT repeat scores alike -> the lists overflow, the selection runs again (shared too)
         r1, r2 = b"ACGT" * 60_000, b"ACGT" * 3000
         for c in (cp, cs, sweep, alone):

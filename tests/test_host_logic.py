@@ -16,7 +16,7 @@ SYMBOLS = [chr(ord("A") + k) for k in range(26)] + ["-"]
 
 def test_library_exports_every_declared_symbol(psa):
     header = open(os.path.join(ROOT, "include", "psa.h")).read()
-    declared = set(re.findall(r"^\s*(?:psa_status|double|void|int|const char\*)\s+(\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^\s*(?:psa_status|double|void|int|long long|const char\*)\s+(\w+)\s*\(", header, re.M))
     assert declared == set(psa.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(psa.lib, name), name
@@ -120,7 +120,7 @@ def test_test_hooks_live_in_the_debug_library_only(psa, psa_debug):
     psa_* product calls (test_only_the_c_abi_is_exported)."""
     import subprocess
     header = open(os.path.join(ROOT, "include", "psa_debug.h")).read()
-    declared = set(re.findall(r"^\s*(?:psa_status|double|void|int|const char\*)\s+(\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^\s*(?:psa_status|double|void|int|long long|const char\*)\s+(\w+)\s*\(", header, re.M))
     assert declared == set(psa.DEBUG_SYMBOLS)
     out = subprocess.run(["nm", "-D", "--defined-only", psa_debug.LIB_PATH], check=True, capture_output=True, text=True).stdout
     names = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
