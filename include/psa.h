@@ -217,6 +217,9 @@ int psa_scratch_shrink_count(psa_context* ctx);
  * shared with other work) leaves, and the tile's last workgroup takes its slice over: this counts those slices — 0 on a
  * GPU the context has to itself.  Synchronises the context's stream; -1 on a device error. */
 long long psa_share_sweep_count(psa_context* ctx);
+/* A search more than half of whose slices had to be taken over tells the context that its GPU is shared: it stops sharing
+ * combines for its next 64 such launches (each then costs what round 4's did) and tries again.  How often that happened. */
+int psa_share_pause_count(psa_context* ctx);
 /* Filter searches of this context whose candidate selection ran twice: candidates are picked
  * against a running bound while the tiles finish; when that overflows the list, the selection
  * is repeated against the final bound (only a second overflow goes to the sequential engine). */

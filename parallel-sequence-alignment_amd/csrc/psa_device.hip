@@ -45,16 +45,17 @@ struct SearchTail {   // everything the host reads back after a search, one D2H 
     int        bad;       // alphabet flag of the encode kernels (bit 0 seq1, bit 1 seq2)
     int        overflow;  // filter engine: the candidate list did not fit
     int        seq;       // echo of the search's sequence number: proves this tail belongs to it
-    int        pad;
+    int        swept;     // fused searches with a shared combine: the slot's sweep counter (low 32 bits) when the search ended
 };
 
 // The tail lives in pinned host memory the host may be POLLING (psa_search_wait does not wait for the kernel's end
 // signal): everything else first, then the search's number as a system-scope release store.
-__device__ __forceinline__ void publish_tail(SearchTail* out, const psa_result& r, int bad, int overflow, int seq)
+__device__ __forceinline__ void publish_tail(SearchTail* out, const psa_result& r, int bad, int overflow, int seq, int swept = 0)
 {
     out->result = r;
     out->bad = bad;
     out->overflow = overflow;
+    out->swept = swept;
     __hip_atomic_store(&out->seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -586,6 +587,13 @@ struct psa_context {
     // bytes of per-chunk counts one search may take: at most 16 GB, and at most half of what the device had free when the
     // context was created; lowered when an allocation of them fails (reserve_chunk_scratch).  Debug library: PSA_SCRATCH_CAP
     size_t      scratch_cap = (size_t)16 << 30;
+    // A shared GPU makes the sharing a loss (the tiles' workgroups are not resident together: +8 us per search): a search
+    // more than half of whose slices had to be taken over pauses the sharing for the context's next kSharePause launches
+    int         share_pause = 0;
+    unsigned    share_swept_seen = 0;        // the sweep counter's low 32 bits after the last sharing search
+    int         pending_share_slices = 0;    // slices other than the last arrivers' own of the sharing search in flight (0: none)
+    int         share_pauses = 0;            // how often that happened
+    bool        share_may_pause = true;      // debug library: PSA_SHARE_PAUSE=0 keeps sharing whatever happens (the sweep path's tests)
     bool        share_combine = true;        // fused multi-chunk searches whose workgroups fit the CUs share the tiles' combine (debug library: PSA_SHARE=0)
     int         share_spins = psa::kShareSpins;   // debug library: PSA_SHARE_SPINS=0 makes every waiting workgroup leave at once (the last arriver sweeps)
     bool        scratch_cap_fitted = false;  // the device's free memory has been looked at (first request beyond 256 MB)
@@ -1233,6 +1241,7 @@ psa::RescoreArgs rescore_args(const psa_context* c, const SearchSlot& s, long lo
     r.bad = c->d_bad;
     r.pairs = pairs;
     r.seq = c->seq;
+    r.share_swept = nullptr;                  // (launch_count: searches that share their tiles' combines)
     r.class_value[0] = t.weights[0];       // get_weight, cuda_funcs.cu:442-452
     r.class_value[1] = -t.weights[1];
     r.class_value[2] = -t.weights[2];
@@ -1370,7 +1379,9 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.share_tag = 0ull;
     a.tile_ready = a.slice_claim = a.share_swept = nullptr;
     a.done_target = p.ntiles;
-    if (fused && inline_select && c->share_combine && p.nchunks > 1 && p.nchunks <= psa::kShareMaxChunks && p.ntiles <= psa::kShareMaxTiles &&
+    if (!raw) c->pending_share_slices = 0;
+    if (fused && inline_select && c->share_combine && c->share_pause > 0 && p.nchunks > 1) --c->share_pause;
+    else if (fused && inline_select && c->share_combine && p.nchunks > 1 && p.nchunks <= psa::kShareMaxChunks && p.ntiles <= psa::kShareMaxTiles &&
         (long long)p.ntiles * p.nchunks <= c->cus) {
         // (every chunk workgroup of every tile is resident at once: they share the tiles' combine + selection)
         constexpr size_t kShareWords = (size_t)psa::kShareMaxTiles * (1 + psa::kShareMaxChunks) + 1;     // (+ the sweep counter)
@@ -1380,6 +1391,7 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
         }
         a.share = 1;
         a.share_tag = ++s.share_launches;
+        c->pending_share_slices = p.ntiles * (p.nchunks - 1);
         if (a.share_spins > 0) {
             // the last chunk of a plan may be shorter than the others (10 rounds as 3 + 3 + 3 + 1): its workgroups arrive that
             // much earlier and must not give up on the others for it — 0.17 us per char of a class (the planner's figure),
@@ -1418,6 +1430,7 @@ psa_status launch_count(psa_context* c, SearchSlot& s, const FilterPlan& p, int 
     a.tail = rescore_args(c, s, (long long)span * s.m, ts);
     a.tail.record_out = c->record_out;
     a.tail.record_shard = c->record_shard;
+    a.tail.share_swept = a.share ? a.share_swept : nullptr;       // (the tail echoes the slot's sweep counter to the host)
     if (fused && s.d_scal == c->slot[0].d_scal) a.tail.best_split = c->slot[0].d_best_split;     // (a slot's own scalars, not a pool entry)
     a.raw1 = a.raw2 = nullptr;
     a.classes_w = nullptr;
@@ -1944,6 +1957,7 @@ psa_status psa_create(int device, void* stream, psa_context** out)
     if (const char* r = std::getenv("PSA_SELECT_FROZEN")) c->select_frozen = std::atoi(r) != 0;
     if (const char* r = std::getenv("PSA_SHARE")) c->share_combine = std::atoi(r) != 0;
     if (const char* r = std::getenv("PSA_SHARE_SPINS")) c->share_spins = std::max(0, std::atoi(r));
+    if (const char* r = std::getenv("PSA_SHARE_PAUSE")) c->share_may_pause = std::atoi(r) != 0;
     if (const char* r = std::getenv("PSA_SCRATCH_CAP")) c->scratch_cap = (size_t)std::atoll(r);     // bytes; sends multi-chunk searches through the piece / sequential paths
 #endif
     *out = c;
@@ -1967,6 +1981,9 @@ long long psa_share_sweep_count(psa_context* c)
         hipMemcpy(&v, c->slot[0].d_share + last, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return (long long)v;
 }
+// How often this context has paused the sharing (64 launches each) because more than half of a search's slices had to be
+// taken over: the GPU was shared with other work.
+int psa_share_pause_count(psa_context* c) { return c ? c->share_pauses : 0; }
 int psa_scratch_fallback_count(psa_context* c) { return c ? c->scratch_fallbacks : 0; }
 int psa_scratch_shrink_count(psa_context* c) { return c ? c->scratch_shrinks : 0; }
 
@@ -2183,6 +2200,22 @@ psa_status psa_search_async(psa_context* c, int first, int last)
 //               order by the sequential engine.
 //   a tail that does not echo this search's number: no workgroup finished it (cannot happen for finite scores):
 //               sequential engine as well.
+// A sharing search has ended normally: how many of its slices had to be taken over by the tiles' last arrivers (the tail
+// echoes the slot's sweep counter)?  More than half: the GPU is shared with other work — no sharing for a while.
+constexpr int kSharePause = 64;
+static void note_share_outcome(psa_context* c)
+{
+    if (c->pending_share_slices <= 0) return;
+    const unsigned now = (unsigned)c->h_tails[0].swept;
+    const unsigned taken = now - c->share_swept_seen;
+    c->share_swept_seen = now;
+    if (c->share_may_pause && (long long)taken * 2 > c->pending_share_slices) {
+        c->share_pause = kSharePause;
+        c->share_pauses += 1;
+    }
+    c->pending_share_slices = 0;
+}
+
 static psa_status settle_search(psa_context* c)
 {
     SearchSlot& s = c->slot[0];
@@ -2216,6 +2249,7 @@ static psa_status settle_search(psa_context* c)
         PSA_HIP(hipStreamSynchronize(c->stream));
     } else {
         s.scal_dirty = false;                     // the search ran to its end: its last workgroup zeroed the scalars
+        note_share_outcome(c);
     }
     return PSA_OK;
 }
@@ -3458,6 +3492,7 @@ psa_status psa_search_sharded(psa_group* g, int first, int last, psa_result* out
             if (st == PSA_OK) g->h_recv[i] = c->h_tails[0].result;
         } else if (c->pending && c->pending_filter && st == PSA_OK) {
             c->slot[0].scal_dirty = false;               // its last workgroup zeroed the search scalars
+            if (c->h_tails[0].seq == c->seq) note_share_outcome(c);      // (the device's own tail has landed with its record)
         }
         if (st == PSA_OK) {
             c->pending = false;

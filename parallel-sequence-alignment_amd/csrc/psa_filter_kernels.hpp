@@ -1102,6 +1102,7 @@ struct RescoreArgs {
     const int*           bad;       // the encode kernels' alphabet flag
     long long            pairs;
     int                  seq;       // sequence number of the search, echoed in the tail
+    const unsigned long long* share_swept;   // shared combines: the slot's sweep counter (echoed in the tail), or NULL
     double class_value[8];          // pair score of class 0..3, +0.0 for the padding class 4
     int m;
     int cap;
@@ -1859,7 +1860,7 @@ __device__ __forceinline__ bool cert_sum(const unsigned char* s_codes, int m, co
 
 // what the host reads after a search (pinned, host-coherent memory written over PCIe by one lane)
 // `bad`: the alphabet flag when the caller has it already (>= 0), else it is loaded here
-__device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const CandRec* best, int status, int bad = -1)
+__device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const CandRec* best, int status, int bad = -1, int swept = 0)
 {
     const bool is_max = a.is_max != 0;
     psa_result r;
@@ -1883,7 +1884,7 @@ __device__ __forceinline__ void write_search_tail(const RescoreArgs& a, const Ca
         x.shard = status ? -2 - status : a.record_shard;
         *a.record_out = x;
     }
-    publish_tail(a.out, r, bad >= 0 ? bad : load_agent(a.bad), status, a.seq);
+    publish_tail(a.out, r, bad >= 0 ? bad : load_agent(a.bad), status, a.seq, swept);
 }
 
 // ---- end of a single search inside the count kernel ---------------------------------
@@ -1962,6 +1963,7 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
         lane < kBestSplit ? (r.best_split ? r.best_split + lane * kBestStride : r.global_best)
         : lane == 8       ? r.global_best
         : lane == 9       ? reinterpret_cast<const unsigned long long*>(r.cand_count)
+        : lane == 11 && r.share_swept ? r.share_swept         // (the slot's sweep counter: the host watches how the sharing goes)
                           : reinterpret_cast<const unsigned long long*>(r.bad);
     const unsigned long long scalar = load_agent(scalar_at);
     double up[2];
@@ -1987,6 +1989,7 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
     }
     const int count = __builtin_amdgcn_readlane((int)scalar, 9);
     const int bad_flag = __builtin_amdgcn_readlane((int)scalar, 10);
+    const int swept = r.share_swept ? __builtin_amdgcn_readlane((int)scalar, 11) : 0;
     const unsigned long long best_key = wave_max_u64(lane <= kBestSplit ? scalar : 0ull);      // the final bound
     if (count > r.cap) {
         // overflow against the running bound: the bound stays in global_best, the host selects once more against it
@@ -2126,9 +2129,9 @@ __device__ __forceinline__ void finish_search(const RescoreArgs& r, unsigned cha
                 idx = k;
         if (idx >= 0) {
             const CandRec b = s_rec[idx];
-            write_search_tail(r, &b, 0, bad_flag);
+            write_search_tail(r, &b, 0, bad_flag, swept);
         } else {
-            write_search_tail(r, nullptr, 0, bad_flag);
+            write_search_tail(r, nullptr, 0, bad_flag, swept);
         }
         // the search scalars are clean for the next search on this slot
         store_agent(r.cand_count, 0);

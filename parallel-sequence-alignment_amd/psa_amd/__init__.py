@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "psa_search_batch", "psa_search_batch_device",
     "psa_search_batch_minmax", "psa_search_batch_minmax_device",
     "psa_fallback_count", "psa_reselect_count", "psa_unfused_count", "psa_duo_retry_count",
-    "psa_scratch_fallback_count", "psa_scratch_shrink_count", "psa_share_sweep_count",
+    "psa_scratch_fallback_count", "psa_scratch_shrink_count", "psa_share_sweep_count", "psa_share_pause_count",
     "psa_group_create", "psa_group_create_ex", "psa_group_destroy", "psa_group_size", "psa_group_set_weights",
     "psa_group_set_seq1", "psa_group_set_seq2", "psa_search_sharded", "psa_search_batch_sharded", "psa_group_last_timing",
     "psa_group_set_timeout",
@@ -117,6 +117,8 @@ def _load() -> C.CDLL:
     if hasattr(lib, "psa_share_sweep_count"):
         lib.psa_share_sweep_count.argtypes = [vp]
         lib.psa_share_sweep_count.restype = C.c_longlong
+    if hasattr(lib, "psa_share_pause_count"):
+        lib.psa_share_pause_count.argtypes = [vp]
     lib.psa_reselect_count.argtypes = [vp]
     lib.psa_duo_retry_count.argtypes = [vp]
     lib.psa_unfused_count.argtypes = [vp]
@@ -422,6 +424,10 @@ class Context:
     def share_sweep_count(self) -> int:
         """Slices of shared combines (offset shards) a tile's last workgroup had to take over (0 on an unshared GPU)."""
         return lib.psa_share_sweep_count(self._h)
+
+    def share_pause_count(self) -> int:
+        """Times the context paused the sharing of combines (64 launches) because its GPU turned out to be shared."""
+        return lib.psa_share_pause_count(self._h)
 
     def scratch_shrink_count(self) -> int:
         """Times a failed allocation of per-chunk counts lowered that cap."""

@@ -1687,7 +1687,10 @@ def test_offset_shards_share_the_tiles_combine(psa, psa_debug, monkeypatch):
     ranges = [psa.shard_range(total, w, r) for w, r in ((2, 1), (4, 0), (4, 3), (8, 0), (8, 5), (8, 7))]
     ranges += [(0, 4000), (4063, 8200), (777_001, 777_001 + 3 * 4064 + 5), (500_000, 500_000 + 6 * 4064), (990_000, 990_001), (5, 37)]
     monkeypatch.setenv("PSA_SHARE_SPINS", "0")
-    sweep = psa_debug.Context(0)
+    paused = psa_debug.Context(0)               # ... and the product's reaction to it: no sharing for the next 64 launches
+    monkeypatch.setenv("PSA_SHARE_PAUSE", "0")
+    sweep = psa_debug.Context(0)                # every launch shares, every owner leaves
+    monkeypatch.delenv("PSA_SHARE_PAUSE")
     monkeypatch.delenv("PSA_SHARE_SPINS")
     monkeypatch.setenv("PSA_SHARE", "0")
     alone = psa_debug.Context(0)
@@ -1695,15 +1698,15 @@ def test_offset_shards_share_the_tiles_combine(psa, psa_debug, monkeypatch):
     t1 = torch.frombuffer(bytearray(s1), dtype=torch.uint8).cuda()
     t2 = torch.frombuffer(bytearray(s2), dtype=torch.uint8).cuda()
     torch.cuda.synchronize()
-    with psa.Context(0) as cp, psa.Context(0) as cs, sweep, alone:
+    with psa.Context(0) as cp, psa.Context(0) as cs, sweep, alone, paused:
         cs.set_engine(psa.ENGINE_SEQUENTIAL)
         for is_max in (True, False):
-            for c in (cp, cs, sweep, alone):
+            for c in (cp, cs, sweep, alone, paused):
                 c.set_weights(W_README, is_max)
                 c.set_sequences(s1, s2)
             for lo, hi in ranges:
                 want = key(cs.search(lo, hi))
-                for c in (cp, sweep, alone):
+                for c in (cp, sweep, alone, paused):
                     assert key(c.search(lo, hi)) == want, (is_max, lo, hi, c is cp, c is sweep)
                     assert key(c.search(lo, hi)) == want                     # (twice: the tags of the previous launch are stale, not zero)
                 assert key(cp.search_device(t1.data_ptr(), n, t2.data_ptr(), m, lo, hi)) == want, (is_max, lo, hi, "one-shot")
@@ -1715,6 +1718,11 @@ def test_offset_shards_share_the_tiles_combine(psa, psa_debug, monkeypatch):
         # one pass per tile); PSA_SHARE=0 has no slices.  (How rarely a PRODUCT workgroup waits in vain on a quiet GPU is a
         # timing matter: tests/test_zz_bench_contract.py.)
         assert sweep.share_sweep_count() > 1000 and alone.share_sweep_count() == 0, (sweep.share_sweep_count(), alone.share_sweep_count())
+        # the same misfortune with the product's reaction left on: a search most of whose slices were taken over pauses the
+        # sharing for the context's next 64 launches — a few sweeps instead of one per launch
+        assert paused.share_pause_count() >= 1 and paused.share_sweep_count() * 10 < sweep.share_sweep_count(), \
+            (paused.share_pause_count(), paused.share_sweep_count(), sweep.share_sweep_count())
+        assert cp.share_pause_count() == 0 and sweep.share_pause_count() == 0
         # ties: every 4th offset of an ACGT repeat scores alike -> the lists overflow, the selection runs again (shared too)
         r1, r2 = b"ACGT" * 60_000, b"ACGT" * 3000
         for c in (cp, cs, sweep, alone):

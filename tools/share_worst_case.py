@@ -20,6 +20,9 @@ if len(sys.argv) > 1:
             print(f"  1/{w} shard: blocking {1e6 * sorted(ts[8:])[16]:.1f} us; slices taken over so far {c.share_sweep_count()}; "
                   f"reselects {c.reselect_count()}, second launches {c.unfused_count()}, sequential fallbacks {c.fallback_count()}")
     sys.exit(0)
-for label, env in (("normal", {}), ("every owner leaves (PSA_SHARE_SPINS=0)", {"PSA_SHARE_SPINS": "0"}), ("no sharing (PSA_SHARE=0)", {"PSA_SHARE": "0"})):
+for label, env in (("normal", {}),
+                   ("every owner leaves, every launch shares (PSA_SHARE_SPINS=0 PSA_SHARE_PAUSE=0)", {"PSA_SHARE_SPINS": "0", "PSA_SHARE_PAUSE": "0"}),
+                   ("every owner leaves, the context reacts: 64 launches without sharing after such a search (PSA_SHARE_SPINS=0)", {"PSA_SHARE_SPINS": "0"}),
+                   ("no sharing (PSA_SHARE=0)", {"PSA_SHARE": "0"})):
     print(label, flush=True)
     subprocess.run([sys.executable, __file__, "child"], env=dict(os.environ, **env))
