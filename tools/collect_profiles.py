@@ -36,6 +36,10 @@ def main():
     prefix = sys.argv[2] if len(sys.argv) > 2 else "prof_" + tag
     src = os.path.join(ROOT, "gpurun_out")
     os.makedirs(OUT, exist_ok=True)
+    # nothing to condense (the profiling call did not run): leave the committed summaries alone
+    if not glob.glob(os.path.join(src, prefix + "_stats", "*", "*_kernel_stats.csv")) or \
+            not glob.glob(os.path.join(src, prefix + "_pmc*", "*", "*_counter_collection.csv")):
+        sys.exit(f"collect_profiles: no rocprofv3 output under gpurun_out/{prefix}_*: profiles/ left as it is")
     for sub, name in (("_stats", f"{tag}_kernel_stats.csv"), ("_twin", f"{tag}_twin_kernel_stats.csv")):
         stats = newest(glob.glob(os.path.join(src, prefix + sub, "*", "*_kernel_stats.csv")))
         if stats:
