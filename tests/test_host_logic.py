@@ -221,6 +221,23 @@ def test_group_needs_a_device(psa):
     assert e.value.status == psa.PSA_ERR_DEVICE
 
 
+def test_null_handles_are_argument_errors_not_crashes(psa):
+    """The round-5 additions of the C ABI take a NULL context / group like the older calls do: an error code or a zero
+    counter, never a crash (no device needed: every check precedes the first HIP call)."""
+    lib = psa.lib
+    assert lib.psa_group_set_timeout(None, 1.0) == psa.PSA_ERR_ARG
+    assert b"psa_group_set_timeout" in lib.psa_last_error()
+    for name in ("psa_scratch_fallback_count", "psa_scratch_shrink_count", "psa_share_pause_count", "psa_fallback_count",
+                 "psa_reselect_count", "psa_unfused_count", "psa_duo_retry_count"):
+        assert getattr(lib, name)(None) == 0, name
+    assert lib.psa_share_sweep_count(None) == 0
+    assert lib.psa_group_size(None) == 0
+    lib.psa_group_destroy(None)                      # (a no-op)
+    out = psa.Result()
+    assert lib.psa_search_sharded(None, 0, 1, C.byref(out), None) == psa.PSA_ERR_ARG
+    assert lib.psa_search_batch_sharded(None, b"A", 1, 1, 1, 0, 1, C.byref(out), None) == psa.PSA_ERR_ARG
+
+
 def _write_record(path, rec):
     w, s1, s2, is_max = rec
     with open(path, "w") as f:
