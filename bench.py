@@ -775,6 +775,16 @@ def main():
                 per_batch[str(w)] = median_us(lambda: ctx.search_batch_device(tq.data_ptr(), nb, m, m, lo_w, hi_w), sync,
                                               reps=5, warm=1) / 1e3
                 ctx.set_sequences_device(p1, n, p2, m)
+        # ... and all the step's queries in flight on the shard (configs[4]'s per-GPU batch under an offset split): the fixed
+        # ~70 us of a batch (launch, planes, the groups' skew, the last epilogue and re-scores) weigh less
+        per_big = {}
+        if nq >= 128:
+            ctx.set_seq1_device(p1, n)
+            for w in (1, 8):
+                lo_w, hi_w = psa.shard_range(total, w, 0)
+                per_big[str(w)] = median_us(lambda: ctx.search_batch_device(tq.data_ptr(), nq, m, m, lo_w, hi_w), sync,
+                                            reps=3, warm=1) / 1e3
+            ctx.set_sequences_device(p1, n, p2, m)
         shard_emulation = {
             "blocking_search_us_per_rank": per_search,
             # slices of shared combines that a tile's last workgroup had to take over (their own workgroups waited in vain):
@@ -783,6 +793,8 @@ def main():
             "blocking_search_speedup_at_8": per_search["1"] / per_search["8"],
             "batch_of_%d_ms_per_rank" % nb: per_batch,
             "batch_speedup_at_8": (per_batch["1"] / per_batch["8"]) if per_batch else None,
+            "batch_of_%d_ms_per_rank" % nq: per_big or None,
+            "batch_of_%d_speedup_at_8" % nq: (per_big["1"] / per_big["8"]) if per_big else None,
             "note": "rank 0's shard of an N-way split timed on ONE GPU (N = 1, 2, 4, 8), exchange not included: an "
                     "emulation, not a scaling measurement.  A single 0.1 ms search is dominated by fixed costs (launch, plane "
                     "build, epilogue, exact re-score) and cannot scale near-linearly; searches in flight do"}
