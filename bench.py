@@ -297,9 +297,17 @@ def group_leg_main(args):
     nq_big = 256 if (n, m) == (1_000_000, 10_000) else min(256, args.queries or 256)
     hq = [psa.generate_sequence_np(SEED_QUERY0 + q, m).tobytes() for q in range(nq_big)]
 
-    def wall_us(fn, reps, warm=3):
+    def wall_us(fn, reps, warm=3, idle=False):
+        """Median wall time of fn(); idle: every device drained before each call (as the parent's latency probes do with
+        torch.cuda.synchronize: a blocking search returns when its result tail lands, a few us before its kernel has
+        retired, so calls back to back would each pay the previous kernel's end)."""
         t = []
         for k in range(reps + warm):
+            if idle:
+                for d in range(have):
+                    hip.hipSetDevice(d)
+                    hip.hipDeviceSynchronize()
+                hip.hipSetDevice(0)
             t0 = time.perf_counter()
             fn()
             if k >= warm:
@@ -315,7 +323,7 @@ def group_leg_main(args):
         ctx.set_seq2(hq[0])
         ref0 = ctx.search(0, total)
         one_result = psa.Result()
-        single_c_call_us = wall_us(lambda: psa.lib.psa_search(ctx._h, 0, total, C.byref(one_result)), 40, warm=5)
+        single_c_call_us = wall_us(lambda: psa.lib.psa_search(ctx._h, 0, total, C.byref(one_result)), 40, warm=5, idle=True)
         ref_batch = ctx.search_batch(hq)
         ref_hi, ref_lo = ctx.search_batch_minmax(hq[:64])
     key = lambda r: (r.score, r.offset, r.char_offset, r.ch)
@@ -333,12 +341,13 @@ def group_leg_main(args):
             def one():
                 g.search(0, total)
                 issue.append(g.last_timing()[0])
-            blocking = wall_us(one, 24)
+            blocking = wall_us(one, 24, idle=True)
             issue = sorted(issue[3:])
             best, records = psa.Result(), (psa.Result * len(devices))()
-            c_call = wall_us(lambda: psa.lib.psa_search_sharded(g._h, 0, total, C.byref(best), records), 40, warm=5)
+            c_call = wall_us(lambda: psa.lib.psa_search_sharded(g._h, 0, total, C.byref(best), records), 40, warm=5, idle=True)
             out["sharded_search"] = {
                 "blocking_us": blocking, "c_call_us": c_call, "single_context_c_call_us": single_c_call_us,
+                "group_cost_us": c_call - single_c_call_us,
                 "host_issue_us": issue[len(issue) // 2], "host_issue_us_max": issue[-1],
                 "pairs_per_s": total * m / (blocking * 1e-6), "equals_single_context": bool(ok),
                 "shard_offsets": [psa.shard_range(total, len(devices), r) for r in (0, len(devices) - 1)]}
@@ -372,8 +381,10 @@ def group_leg_main(args):
     print(json.dumps({"mode": mode, "visible_devices": have, "groups": legs, "ok": all(l["ok"] for l in legs),
                       "note": "psa_search_sharded / psa_search_batch_sharded through psa.Group (ctypes): configs[3] = one blocking "
                               "1M x 10k MAX search, offsets sharded; configs[4] = 64 / 256 queries dealt to the devices.  "
-                              "c_call_us / single_context_c_call_us = the bare C entry points (psa_search_sharded / psa_search of one context), same "
-                              "process, buffers allocated beforehand: their difference is what the group and its exchange add; "
+                              "blocking_us = through the Python binding, c_call_us / single_context_c_call_us = the bare C entry points "
+                              "(psa_search_sharded / psa_search of one context), same process, buffers allocated beforehand, the "
+                              "devices idle before every call: c_call_us - single_context_c_call_us is what the group and its "
+                              "exchange add; "
                               "host_issue_us = from the call's entry until the LAST device's launch had been enqueued (persistent "
                               "launcher thread per device; one thread issuing 8 launches in turn took ~40 us).  N > 1 with RCCL has "
                               "only ever run where this object says exchange = RCCL with more than one device"}), flush=True)

@@ -59,7 +59,7 @@ def test_bench_group_of_one_costs_little_more_than_a_context(bench_line):
     timed at the bare C entry points in one process (the exchange's fixed cost: the all-gather's enqueue, the publish
     kernel behind the search kernel, the polled flag; round 4, with a D2H copy and a stream synchronisation: +15..19)."""
     one = bench_line["c_abi_group"]["groups"][0]["sharded_search"]
-    assert one["c_call_us"] - one["single_context_c_call_us"] < 12.0, one
+    assert one["group_cost_us"] == one["c_call_us"] - one["single_context_c_call_us"] and one["group_cost_us"] < 12.0, one
 
 
 @pytest.mark.parametrize("n,m", [(1_000_000, 400_000)])
