@@ -1862,6 +1862,19 @@ def test_chunk_counts_that_cannot_be_allocated_lower_the_cap(psa, psa_debug, mon
         assert key(cd.search(1000, 20_000)) == key(cp.search(1000, 20_000))           # a small range still fits: filter engine
         assert cd.scratch_fallback_count() == 1 and cd.fallback_count() == 0
         assert cp.scratch_shrink_count() == 0 and cp.scratch_fallback_count() == 0
+        # batches keep their chunk counts in two ring buffers of their own: the lowered cap sends this one to the sequential
+        # engine too ...
+        cd.set_seq1(s1)
+        cp.set_seq1(s1)
+        q2 = psa.generate_sequence(883, m)
+        want_batch = [key(r) for r in cp.search_batch([s2, q2])]
+        assert [key(r) for r in cd.search_batch([s2, q2])] == want_batch and cd.scratch_fallback_count() == 2
+    # ... and a context whose FIRST multi-chunk request is a batch finds out there (the ring buffers' allocation fails)
+    with psa_debug.Context(0) as cb:
+        cb.set_weights(W_README, True)
+        cb.set_seq1(s1)
+        assert [key(r) for r in cb.search_batch([s2, q2])] == want_batch
+        assert cb.scratch_shrink_count() == 1 and cb.scratch_fallback_count() == 1 and cb.fallback_count() == 0
 
 
 def key_of(want):
