@@ -307,3 +307,16 @@ def test_stock_reference_caller_links(psa, tmp_path):
                     "-L", lib_dir, "-lpsa_amd", f"-Wl,-rpath,{lib_dir}"], check=True, capture_output=True, text=True)
     undefined = subprocess.run(["nm", "-u", str(exe)], check=True, capture_output=True, text=True).stdout
     assert psa.CXX_GPU_RUN_PROGRAM in undefined
+
+
+def test_reference_make_targets(tmp_path, psa):
+    """`make runseq RUNDIR=...` (the reference's own target name, Makefile:19-20: one host thread, no GPU) on the bundled
+    input.txt writes the reference's output.txt byte for byte."""
+    import shutil
+    import subprocess
+    from conftest import GOLDEN, PKG
+    shutil.copy(os.path.join(GOLDEN, "reference_input.txt"), tmp_path / "input.txt")
+    run = subprocess.run(["make", "-C", PKG, "runseq", f"RUNDIR={tmp_path}"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr[-2000:]
+    assert "total time:" in run.stdout
+    assert (tmp_path / "output.txt").read_bytes() == open(os.path.join(GOLDEN, "reference_output.txt"), "rb").read()
