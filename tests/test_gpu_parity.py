@@ -1079,6 +1079,19 @@ def test_drop_in_program_hybrid_split(psa, oracle, reference_records, tmp_path, 
         assert (d / "output.txt").read_text() == _expected_output(oracle, reference_records[rec]), rec
 
 
+def test_reference_make_run_target(psa, tmp_path):
+    """`make run RUNDIR=... DEVICES=0` (the reference's `run` target, Makefile:21-22 — there two MPI ranks on two machines,
+    here the GPUs listed in DEVICES, one process): the bundled input.txt -> the reference's output.txt, byte for byte."""
+    import shutil
+    import subprocess
+    from conftest import PKG
+    shutil.copy(os.path.join(GOLDEN, "reference_input.txt"), tmp_path / "input.txt")
+    run = subprocess.run(["make", "-C", PKG, "run", f"RUNDIR={tmp_path}", "DEVICES=0"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr[-2000:]
+    assert "CUDA percentage set to 100" in run.stdout
+    assert (tmp_path / "output.txt").read_bytes() == open(os.path.join(GOLDEN, "reference_output.txt"), "rb").read()
+
+
 @pytest.mark.parametrize("extra", [["--scaling", "weak"], ["--scaling", "strong"], ["--mode", "shard"]])
 def test_bench_n_rank_paths_rehearsed_on_one_gpu(psa, extra):
     """bench.py's N > 1 code paths on real hardware as far as a one-GPU box allows: `--gpus 2` launches two ranks
