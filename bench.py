@@ -804,8 +804,8 @@ def main():
             "blocking_search_speedup_at_8": per_search["1"] / per_search["8"],
             "batch_of_%d_ms_per_rank" % nb: per_batch,
             "batch_speedup_at_8": (per_batch["1"] / per_batch["8"]) if per_batch else None,
-            "batch_of_%d_ms_per_rank" % nq: per_big or None,
-            "batch_of_%d_speedup_at_8" % nq: (per_big["1"] / per_big["8"]) if per_big else None,
+            **({"batch_of_%d_ms_per_rank" % nq: per_big, "batch_of_%d_speedup_at_8" % nq: per_big["1"] / per_big["8"]}
+               if per_big else {}),
             "note": "rank 0's shard of an N-way split timed on ONE GPU (N = 1, 2, 4, 8), exchange not included: an "
                     "emulation, not a scaling measurement.  A single 0.1 ms search is dominated by fixed costs (launch, plane "
                     "build, epilogue, exact re-score) and cannot scale near-linearly; searches in flight do"}
