@@ -49,9 +49,10 @@ def test_bench_offset_shard_scales(bench_line):
 
 def test_bench_shards_share_their_combines_undisturbed(bench_line):
     """On a GPU the bench has to itself practically no chunk workgroup of a shard waits in vain for its tile's peers (a
-    slice taken over by the tile's last workgroup costs that tile ~9 us): fewer than 1 % of the ~4,000 slices of the probe."""
+    slice taken over by the tile's last workgroup costs that tile ~9 us): a few of the ~4,000 slices of the probe at most
+    (0 to 6 over a dozen runs; a GPU that is shared shows thousands)."""
     taken = bench_line["shard_emulation"]["slices_taken_over"]
-    assert taken is not None and 0 <= taken < 40, taken
+    assert taken is not None and 0 <= taken < 200, taken
 
 
 def test_bench_group_of_one_costs_little_more_than_a_context(bench_line):
